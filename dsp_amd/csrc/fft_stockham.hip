@@ -1,0 +1,623 @@
+// Batched complex FFT for gfx950: Stockham autosort passes, one frame per
+// group of NT lanes, intermediate passes exchanged through a padded LDS image.
+//
+// A frame of N points is owned by NT = N/P lanes (P points per lane held in
+// registers).  Each pass p of radix R:
+//
+//   j  = butterfly index, lane-contiguous (lane + NT*b)
+//   v[r]  = src[j + r*N/R]                       (global for the first pass)
+//   v[r] *= W_{Ns*R}^{(j mod Ns)*r}               (Ns = product of earlier radices)
+//   v     = DFT_R(v)                              (in registers)
+//   dst[(j div Ns)*Ns*R + (j mod Ns) + r*Ns] = v[r]   (global for the last pass)
+//
+// Input and output are in natural order, so no bit-reversal pass exists.  The
+// twiddles come from a table built in double precision on the host; for the
+// f32 kernels each lane fetches its (frame-independent) twiddles once and
+// keeps them in registers while it loops over frames.  When NT <= 64 a frame
+// lives inside one wave and the passes need no workgroup barrier.
+//
+// Semantics are those of fftw_plan_dft_1d as the reference calls it
+// (fftc/main.c:31-43): unnormalised in both directions, sign -1 forward.
+// The backward transform is conj(forward(conj(x))).
+#include "common.h"
+
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+namespace {
+
+template <typename T>
+struct alignas(2 * sizeof(T)) C {
+    T re, im;
+};
+
+template <typename T> __device__ __forceinline__ C<T> operator+(C<T> a, C<T> b) { return {a.re + b.re, a.im + b.im}; }
+template <typename T> __device__ __forceinline__ C<T> operator-(C<T> a, C<T> b) { return {a.re - b.re, a.im - b.im}; }
+template <typename T> __device__ __forceinline__ C<T> cmul(C<T> a, C<T> b)
+{
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+// multiply by -i (forward quarter turn)
+template <typename T> __device__ __forceinline__ C<T> mul_mi(C<T> a) { return {a.im, -a.re}; }
+
+// cos/sin of 2*pi*k/16, k = 0..15
+__device__ constexpr double kCos16[16] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+                                          0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
+                                          -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173,
+                                          0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
+__device__ constexpr double kSin16[16] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
+                                          1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
+                                          0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
+                                          -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173};
+
+// a * exp(-2*pi*i*K/16), K a compile-time constant; trivial factors cost no multiply
+template <int K, typename T>
+__device__ __forceinline__ C<T> mul_w16(C<T> a)
+{
+    constexpr int k = K & 15;
+    if constexpr (k == 0) return a;
+    else if constexpr (k == 4) return mul_mi(a);
+    else if constexpr (k == 8) return {-a.re, -a.im};
+    else if constexpr (k == 12) return {-a.im, a.re};
+    else {
+        constexpr T c = (T)kCos16[k], s = (T)(-kSin16[k]);
+        return {a.re * c - a.im * s, a.re * s + a.im * c};
+    }
+}
+
+// t[a*RB + c] *= W_R^{a*c} for every element of the RA x RB intermediate
+template <int R, int RB, typename T, int... I>
+__device__ __forceinline__ void inner_twiddle(C<T> *t, std::integer_sequence<int, I...>)
+{
+    ((t[I] = mul_w16<(I / RB) * (I % RB) * (16 / R)>(t[I])), ...);
+}
+
+// Forward DFT of R points held in v[0], v[S], v[2S], ... (natural order in and out).
+template <int R, int S, typename T>
+__device__ __forceinline__ void dft_reg(C<T> *v)
+{
+    if constexpr (R == 1) {
+    } else if constexpr (R == 2) {
+        C<T> a = v[0], b = v[S];
+        v[0] = a + b;
+        v[S] = a - b;
+    } else if constexpr (R == 4) {
+        C<T> t0 = v[0] + v[2 * S], t1 = v[0] - v[2 * S];
+        C<T> t2 = v[S] + v[3 * S], t3 = mul_mi(v[S] - v[3 * S]);
+        v[0] = t0 + t2;
+        v[S] = t1 + t3;
+        v[2 * S] = t0 - t2;
+        v[3 * S] = t1 - t3;
+    } else {
+        // R = RA*RB, n = a + RA*b, k = c + RB*d
+        constexpr int RA = (R == 8) ? 2 : 4, RB = R / RA;
+        C<T> t[R];
+#pragma unroll
+        for (int a = 0; a < RA; a++) {
+#pragma unroll
+            for (int b = 0; b < RB; b++) t[a * RB + b] = v[(a + RA * b) * S];
+            dft_reg<RB, 1>(&t[a * RB]);  // t[a][c]
+        }
+        // twiddle t[a][c] by W_R^{a*c}, then RA-point DFTs over a
+        inner_twiddle<R, RB>(t, std::make_integer_sequence<int, R>{});
+#pragma unroll
+        for (int c = 0; c < RB; c++) {
+            dft_reg<RA, RB>(&t[c]);  // over a, stride RB -> index d
+#pragma unroll
+            for (int d = 0; d < RA; d++) v[(c + RB * d) * S] = t[d * RB + c];
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned pad(unsigned i) { return i + (i >> 4); }
+constexpr unsigned padded_len(unsigned n) { return n + (n >> 4) + 1; }
+
+template <int NT>
+__device__ __forceinline__ void frame_sync()
+{
+    if constexpr (NT > 64) {
+        __syncthreads();
+    } else {
+        // the frame's lanes are in one wave: LDS operations of a wave complete in
+        // issue order, so only the compiler has to be kept from reordering them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// Number of twiddle registers (complex) pass `R` with P points per lane needs.
+constexpr int tw_count(int P, int R, int NS) { return (R > 1 && NS > 1) ? (P / R) * (R - 1) : 0; }
+
+template <typename T, int N, int NT, int R, int NS>
+__device__ __forceinline__ void load_twiddles(C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
+{
+    constexpr int P = N / NT;
+    if constexpr (R > 1 && NS > 1) {
+#pragma unroll
+        for (int b = 0; b < P / R; b++) {
+            const unsigned j = tl + NT * b;
+            const unsigned k = j % NS;
+#pragma unroll
+            for (int r = 1; r < R; r++) twr[b * (R - 1) + r - 1] = tw[k * r * (N / (NS * R))];
+        }
+    }
+}
+
+// One pass over the P register-resident points of this lane.
+//   FIRST: sources are v as loaded from global by the caller; otherwise read from LDS
+//   LAST : results stay in v (caller stores to global); otherwise written to LDS
+template <typename T, int N, int NT, int R, int NS, bool FIRST, bool LAST, bool TWREG>
+__device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
+{
+    constexpr int P = N / NT, NB = P / R;
+    if constexpr (R == 1) return;
+    if constexpr (!FIRST) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < R; r++) v[b * R + r] = lds[pad(tl + NT * b + r * (N / R))];
+        frame_sync<NT>();
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        if constexpr (NS > 1) {
+            const unsigned k = (tl + NT * b) % NS;
+#pragma unroll
+            for (int r = 1; r < R; r++) {
+                C<T> w;
+                if constexpr (TWREG) w = twr[b * (R - 1) + r - 1];
+                else w = tw[k * r * (N / (NS * R))];
+                v[b * R + r] = cmul(v[b * R + r], w);
+            }
+        }
+        dft_reg<R, 1>(&v[b * R]);
+    }
+    if constexpr (!LAST) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const unsigned j = tl + NT * b;
+            const unsigned j0 = (j / NS) * (NS * R) + (j % NS);
+#pragma unroll
+            for (int r = 0; r < R; r++) lds[pad(j0 + r * NS)] = v[b * R + r];
+        }
+        frame_sync<NT>();
+    }
+}
+
+template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
+
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, bool TWREG>
+__global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T> *in, C<T> *out,
+                                                                      const C<T> *__restrict__ tw, size_t batch,
+                                                                      int backward)
+{
+    static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
+    constexpr int P = N / NT;
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;  // frames per workgroup per iteration
+    constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
+    constexpr int NSLAST = N / RLAST;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned slot = threadIdx.x / NT;
+    const unsigned tl = threadIdx.x % NT;
+    C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
+
+    C<T> tw1[cmax(1, TWREG ? tw_count(P, R1, NS1) : 0)];
+    C<T> tw2[cmax(1, TWREG ? tw_count(P, R2, NS2) : 0)];
+    C<T> tw3[cmax(1, TWREG ? tw_count(P, R3, NS3) : 0)];
+    if constexpr (TWREG) {
+        load_twiddles<T, N, NT, R1, NS1>(tw1, tw, tl);
+        load_twiddles<T, N, NT, R2, NS2>(tw2, tw, tl);
+        load_twiddles<T, N, NT, R3, NS3>(tw3, tw, tl);
+    }
+    const T sgn = backward ? T(-1) : T(1);
+
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const size_t frame = fb * FPB + slot;
+        const bool active = frame < batch;
+        const C<T> *src = in + frame * N;
+        C<T> *dst = out + frame * N;
+
+        C<T> v[P];
+        // first pass reads global memory: lane-contiguous, R0 loads N/R0 apart
+#pragma unroll
+        for (int b = 0; b < P / R0; b++)
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                C<T> q = {T(0), T(0)};
+                if (active) q = src[tl + NT * b + r * (N / R0)];
+                q.im *= sgn;
+                v[b * R0 + r] = q;
+            }
+
+        fft_pass<T, N, NT, R0, 1, true, NPASS == 1, TWREG>(v, lds, nullptr, tw, tl);
+        if constexpr (R1 > 1) fft_pass<T, N, NT, R1, NS1, false, NPASS == 2, TWREG>(v, lds, tw1, tw, tl);
+        if constexpr (R2 > 1) fft_pass<T, N, NT, R2, NS2, false, NPASS == 3, TWREG>(v, lds, tw2, tw, tl);
+        if constexpr (R3 > 1) fft_pass<T, N, NT, R3, NS3, false, NPASS == 4, TWREG>(v, lds, tw3, tw, tl);
+
+        // last pass writes global memory: butterfly j, output r goes to j + r*N/RLAST
+        if (active) {
+#pragma unroll
+            for (int b = 0; b < P / RLAST; b++)
+#pragma unroll
+                for (int r = 0; r < RLAST; r++) {
+                    C<T> q = v[b * RLAST + r];
+                    q.im *= sgn;
+                    dst[tl + NT * b + r * NSLAST] = q;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// real <-> half-complex helpers (length n even): one complex FFT of n/2 points
+// plus an O(n) split / merge step.
+// ---------------------------------------------------------------------------
+
+// Z = FFT_{n/2}(x[2m] + i x[2m+1]);  X[k] = E[k] + W_n^k O[k], k = 0..n/2, with
+// E[k] = (Z[k] + conj Z[h-k])/2, O[k] = -i (Z[k] - conj Z[h-k])/2, h = n/2, Z[h] = Z[0].
+template <typename T>
+__global__ __launch_bounds__(256) void r2c_split_kernel(const C<T> *__restrict__ z, C<T> *__restrict__ xout,
+                                                        const C<T> *__restrict__ twn, unsigned n, size_t batch)
+{
+    const unsigned h = n / 2;
+    const size_t total = batch * (size_t)(h + 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / (h + 1);
+        const unsigned k = (unsigned)(i - f * (h + 1));
+        const C<T> *zf = z + f * h;
+        const C<T> a = zf[k == h ? 0 : k];
+        const C<T> b0 = zf[(h - k) % h];
+        const C<T> b = {b0.re, -b0.im};
+        const C<T> e = {(a.re + b.re) * T(0.5), (a.im + b.im) * T(0.5)};
+        const C<T> d = {(a.re - b.re) * T(0.5), (a.im - b.im) * T(0.5)};
+        const C<T> o = {d.im, -d.re};  // -i * d
+        const C<T> w = (k == h) ? C<T>{T(-1), T(0)} : twn[k];  // exp(-2 pi i k / n)
+        const C<T> wo = cmul(w, o);
+        xout[f * (h + 1) + k] = {e.re + wo.re, e.im + wo.im};
+    }
+}
+
+// Inverse of the split, unnormalised c2r: x = IFFT_n(Hermitian X) (scale n) equals the
+// n/2-point backward transform of Z[k] = (X[k] + conj X[h-k]) + i W_n^{-k} (X[k] - conj X[h-k]).
+template <typename T>
+__global__ __launch_bounds__(256) void c2r_merge_kernel(const C<T> *__restrict__ xin, C<T> *__restrict__ z,
+                                                        const C<T> *__restrict__ twn, unsigned n, size_t batch)
+{
+    const unsigned h = n / 2;
+    const size_t total = batch * (size_t)h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / h;
+        const unsigned k = (unsigned)(i - f * h);
+        const C<T> *xf = xin + f * (h + 1);
+        C<T> a = xf[k];
+        C<T> b0 = xf[h - k];
+        // like FFTW's c2r, ignore the imaginary parts of the DC and Nyquist bins
+        if (k == 0) { a.im = T(0); b0.im = T(0); }
+        const C<T> b = {b0.re, -b0.im};
+        const C<T> s = {a.re + b.re, a.im + b.im};
+        const C<T> d = {a.re - b.re, a.im - b.im};
+        const C<T> w0 = twn[k];
+        const C<T> w = {w0.re, -w0.im};  // exp(+2 pi i k / n)
+        const C<T> wd = cmul(w, d);
+        z[f * h + k] = {s.re - wd.im, s.im + wd.re};  // s + i * wd
+    }
+}
+
+// out[f][k] = in[f][k] * g[k]  (real gain per bin; util/filter/filter.c:92-96)
+template <typename T>
+__global__ __launch_bounds__(256) void bin_gain_kernel(C<T> *__restrict__ bins, const T *__restrict__ g,
+                                                       unsigned nbin, size_t batch)
+{
+    const size_t total = batch * (size_t)nbin;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const T gg = g[i % nbin];
+        C<T> v = bins[i];
+        v.re *= gg;
+        v.im *= gg;
+        bins[i] = v;
+    }
+}
+
+// out[f][i] = 2*|bins[f][i]| / scale, i < nout (fftc/main.c:80-105, fir/src/main.c:246-251)
+template <typename T>
+__global__ __launch_bounds__(256) void ps_abs_kernel(const C<T> *__restrict__ bins, T *__restrict__ out, unsigned nout,
+                                                     T scale, size_t batch, unsigned in_stride)
+{
+    const size_t total = batch * (size_t)nout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / nout;
+        const C<T> v = bins[f * in_stride + (i - f * nout)];
+        out[i] = (T(2) * sqrt(v.re * v.re + v.im * v.im)) / scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T *__restrict__ x, T divisor, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = x[i] / divisor;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+
+typedef int (*fft_launch_fn)(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu,
+                             hipStream_t s);
+
+struct dspmi_fft_plan {
+    int device;
+    int precision;
+    unsigned n;
+    int num_cu;
+    void *tw_n;       // exp(-2 pi i k / n), k < n (c2c twiddles; also the r2c split factors)
+    void *tw_half;    // exp(-2 pi i k / (n/2)) for the half-length transform of r2c / c2r (n even)
+    void *work;       // scratch for r2c / c2r: batch_cap * (n/2) complex
+    size_t work_cap;  // in frames
+    fft_launch_fn launch;
+    fft_launch_fn launch_half;
+    char name[64];
+};
+
+namespace {
+
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, bool TWREG>
+int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
+{
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr bool single_pass = R1 == 1 && R2 == 1 && R3 == 1;  // global -> registers -> global
+    constexpr size_t lds = single_pass ? 0 : (size_t)FPB * padded_len(N) * sizeof(C<T>);
+    auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TWREG>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+        attr_set = true;
+    }
+    if (batch == 0) return DSPMI_OK;
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    // enough workgroups to fill every CU several times over; each loops over frames
+    size_t per_cu = lds ? (160 * 1024) / lds : 8;
+    if (per_cu > 2048 / BT) per_cu = 2048 / BT;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = (size_t)num_cu * per_cu;
+    if (grid > nfb) grid = nfb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in),
+                       static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), batch, backward);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+struct FftEntry {
+    unsigned n;
+    fft_launch_fn fn;
+    const char *name;
+};
+
+#define F32(N, NT, A, B, C_, D) {N, launch_c2c<float, N, NT, A, B, C_, D, true>, "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
+#define F64(N, NT, A, B, C_, D) {N, launch_c2c<double, N, NT, A, B, C_, D, false>, "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
+
+const FftEntry kF32[] = {
+    F32(2, 1, 2, 1, 1, 1),          F32(4, 1, 4, 1, 1, 1),          F32(8, 1, 8, 1, 1, 1),
+    F32(16, 1, 16, 1, 1, 1),        F32(32, 2, 16, 2, 1, 1),        F32(64, 4, 16, 4, 1, 1),
+    F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
+    F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),   F32(4096, 256, 16, 16, 16, 1),
+    F32(8192, 512, 16, 16, 16, 2),  F32(16384, 1024, 16, 16, 16, 4),
+};
+const FftEntry kF64[] = {
+    F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),
+    F64(16, 2, 8, 2, 1, 1),       F64(32, 4, 8, 4, 1, 1),        F64(64, 8, 8, 8, 1, 1),
+    F64(128, 16, 8, 8, 2, 1),     F64(256, 32, 8, 8, 4, 1),      F64(512, 64, 8, 8, 8, 1),
+    F64(1024, 128, 8, 8, 8, 2),   F64(2048, 256, 8, 8, 8, 4),    F64(4096, 512, 8, 8, 8, 8),
+    F64(8192, 512, 16, 16, 16, 2),
+};
+
+const FftEntry *find_entry(unsigned n, int precision)
+{
+    const FftEntry *tab = precision == DSPMI_F64 ? kF64 : kF32;
+    const size_t cnt = precision == DSPMI_F64 ? sizeof(kF64) / sizeof(kF64[0]) : sizeof(kF32) / sizeof(kF32[0]);
+    for (size_t i = 0; i < cnt; i++)
+        if (tab[i].n == n) return &tab[i];
+    return nullptr;
+}
+
+template <typename T>
+int upload_twiddles(void **dev, unsigned n)
+{
+    std::vector<C<T>> tw(n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (unsigned k = 0; k < n; k++) {
+        const long double a = -two_pi * (long double)k / (long double)n;
+        tw[k].re = (T)cosl(a);
+        tw[k].im = (T)sinl(a);
+    }
+    DSPMI_HIP(hipMalloc(dev, n * sizeof(C<T>)));
+    DSPMI_HIP(hipMemcpy(*dev, tw.data(), n * sizeof(C<T>), hipMemcpyHostToDevice));
+    return DSPMI_OK;
+}
+
+int ensure_work(dspmi_fft_plan *pl, size_t batch)
+{
+    if (batch <= pl->work_cap) return DSPMI_OK;
+    if (pl->work) DSPMI_HIP(hipFree(pl->work));
+    pl->work = nullptr;
+    pl->work_cap = 0;
+    const size_t esz = pl->precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
+    DSPMI_HIP(hipMalloc(&pl->work, batch * (size_t)(pl->n / 2) * esz));
+    pl->work_cap = batch;
+    return DSPMI_OK;
+}
+
+inline unsigned ew_grid(size_t total, int num_cu)
+{
+    size_t g = (total + 255) / 256;
+    const size_t cap = (size_t)num_cu * 8;
+    return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
+{
+    if (!plan || n == 0) return dspmi::fail(DSPMI_EINVAL, "fft_create: null plan pointer or n == 0");
+    if (precision != DSPMI_F32 && precision != DSPMI_F64) return dspmi::fail(DSPMI_EINVAL, "fft_create: bad precision");
+    const FftEntry *e = n == 1 ? nullptr : find_entry(n, precision);
+    const FftEntry *eh = (n % 2 == 0 && n >= 4) ? find_entry(n / 2, precision) : nullptr;
+    if (!e && !eh && n != 1)
+        return dspmi::fail(DSPMI_ENOSYS, "fft_create: no kernel for n = %u (%s)", n, precision == DSPMI_F64 ? "f64" : "f32");
+    if (device < 0) DSPMI_HIP(hipGetDevice(&device));
+    int prev = 0;
+    DSPMI_HIP(hipGetDevice(&prev));
+    DSPMI_HIP(hipSetDevice(device));
+    dspmi_fft_plan *pl = new dspmi_fft_plan();
+    pl->device = device;
+    pl->precision = precision;
+    pl->n = n;
+    pl->launch = e ? e->fn : nullptr;
+    pl->launch_half = eh ? eh->fn : nullptr;
+    snprintf(pl->name, sizeof pl->name, "%s", e ? e->name : (eh ? eh->name : "fft_n1"));
+    hipDeviceProp_t prop;
+    int rc = DSPMI_OK;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = dspmi::fail(DSPMI_EIO, "fft_create: hipGetDeviceProperties failed");
+    pl->num_cu = rc == DSPMI_OK ? prop.multiProcessorCount : 256;
+    if (rc == DSPMI_OK)
+        rc = precision == DSPMI_F64 ? upload_twiddles<double>(&pl->tw_n, n) : upload_twiddles<float>(&pl->tw_n, n);
+    if (rc == DSPMI_OK && eh)
+        rc = precision == DSPMI_F64 ? upload_twiddles<double>(&pl->tw_half, n / 2) : upload_twiddles<float>(&pl->tw_half, n / 2);
+    (void)hipSetDevice(prev);
+    if (rc != DSPMI_OK) {
+        dspmi_fft_destroy(pl);
+        return rc;
+    }
+    *plan = pl;
+    return DSPMI_OK;
+}
+
+int dspmi_fft_destroy(dspmi_fft_t plan)
+{
+    if (!plan) return DSPMI_OK;
+    if (plan->tw_n) (void)hipFree(plan->tw_n);
+    if (plan->tw_half) (void)hipFree(plan->tw_half);
+    if (plan->work) (void)hipFree(plan->work);
+    delete plan;
+    return DSPMI_OK;
+}
+
+int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, int sign, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null plan");
+    if (sign != DSPMI_FORWARD && sign != DSPMI_BACKWARD) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: sign must be -1 or +1");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->n == 1) {
+        if (in != out) {
+            const size_t esz = plan->precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
+            DSPMI_HIP(hipMemcpyAsync(out, in, batch * esz, hipMemcpyDeviceToDevice, s));
+        }
+        return DSPMI_OK;
+    }
+    if (!plan->launch) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_c2c: no complex kernel for n = %u", plan->n);
+    return plan->launch(in, out, plan->tw_n, batch, sign == DSPMI_BACKWARD, plan->num_cu, s);
+}
+
+int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null plan");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null buffer");
+    if (plan->n % 2 || !plan->launch_half)
+        return dspmi::fail(DSPMI_ENOSYS, "fft_exec_r2c: n = %u needs an even length with a half-length kernel", plan->n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = ensure_work(plan, batch);
+    if (rc != DSPMI_OK) return rc;
+    // the real frame [n] reinterpreted as n/2 complex points is the packed input
+    rc = plan->launch_half(in, plan->work, plan->tw_half, batch, 0, plan->num_cu, s);
+    if (rc != DSPMI_OK) return rc;
+    const size_t total = batch * (size_t)(plan->n / 2 + 1);
+    if (plan->precision == DSPMI_F64)
+        hipLaunchKernelGGL(r2c_split_kernel<double>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<double> *>(plan->work), static_cast<C<double> *>(out),
+                           static_cast<const C<double> *>(plan->tw_n), plan->n, batch);
+    else
+        hipLaunchKernelGGL(r2c_split_kernel<float>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<float> *>(plan->work), static_cast<C<float> *>(out),
+                           static_cast<const C<float> *>(plan->tw_n), plan->n, batch);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null plan");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null buffer");
+    if (plan->n % 2 || !plan->launch_half)
+        return dspmi::fail(DSPMI_ENOSYS, "fft_exec_c2r: n = %u needs an even length with a half-length kernel", plan->n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = ensure_work(plan, batch);
+    if (rc != DSPMI_OK) return rc;
+    const size_t total = batch * (size_t)(plan->n / 2);
+    if (plan->precision == DSPMI_F64)
+        hipLaunchKernelGGL(c2r_merge_kernel<double>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<double> *>(in), static_cast<C<double> *>(plan->work),
+                           static_cast<const C<double> *>(plan->tw_n), plan->n, batch);
+    else
+        hipLaunchKernelGGL(c2r_merge_kernel<float>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<float> *>(in), static_cast<C<float> *>(plan->work),
+                           static_cast<const C<float> *>(plan->tw_n), plan->n, batch);
+    DSPMI_HIP(hipGetLastError());
+    return plan->launch_half(plan->work, out, plan->tw_half, batch, 1, plan->num_cu, s);
+}
+
+const char *dspmi_fft_variant(dspmi_fft_t plan)
+{
+    return plan ? plan->name : "";
+}
+
+}  // extern "C"
+
+// Element-wise helpers used by the host wrappers (same translation unit so the
+// kernels above stay file-local).
+namespace dspmi {
+
+int bin_gain_f64(void *bins, const double *gain_dev, unsigned nbin, size_t batch, int num_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(bin_gain_kernel<double>, dim3(ew_grid(batch * nbin, num_cu)), dim3(256), 0, s,
+                       static_cast<C<double> *>(bins), gain_dev, nbin, batch);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride,
+               hipStream_t s)
+{
+    hipLaunchKernelGGL(ps_abs_kernel<double>, dim3(ew_grid(batch * nout, 256)), dim3(256), 0, s,
+                       static_cast<const C<double> *>(bins), out, nout, scale, batch, in_stride);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int scale_f64(double *x, double divisor, size_t total, int num_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_kernel<double>, dim3(ew_grid(total, num_cu)), dim3(256), 0, s, x, divisor, total);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+}  // namespace dspmi

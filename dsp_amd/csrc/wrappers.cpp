@@ -1,0 +1,176 @@
+// Host drop-in wrappers: the reference's C signatures over the device kernels.
+//
+// Each call stages its host double buffers to the device, runs the double
+// precision kernels and blocks until the result is back in host memory -- the
+// synchronous, caller-owned-buffer behaviour of the reference's static
+// routines.  Any device failure prints the failing call and abort()s: these
+// routines return void in the reference, and there is no CPU fallback.
+#include "common.h"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+int dspmi_fir_exec_f64_desc(dspmi_fir_t plan, double *y, size_t y_stride, unsigned nxx, const double *x,
+                            size_t x_stride, unsigned nx, unsigned nchan, unsigned flags, void *stream);
+
+namespace dspmi {
+int bin_gain_f64(void *bins, const double *gain_dev, unsigned nbin, size_t batch, int num_cu, hipStream_t s);
+int scale_f64(double *x, double divisor, size_t total, int num_cu, hipStream_t s);
+int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride,
+               hipStream_t s);
+}  // namespace dspmi
+
+namespace {
+
+// RAII device buffer for the wrapper path.
+struct DevBuf {
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) { DSPMI_HIP_OR_DIE(hipMalloc(&p, bytes ? bytes : 8)); }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+enum Order { ASCENDING, DESCENDING };
+
+void run_fir(double *y, unsigned nxx, const double *x, unsigned nx, const double *h, unsigned nh, unsigned flags,
+             Order order)
+{
+    if (nxx == 0) return;
+    if (nh == 0) {  // an empty tap set sums nothing
+        std::memset(y, 0, (size_t)nxx * sizeof(double));
+        return;
+    }
+    dspmi_fir_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fir_create_f64(&plan, h, nh, -1));
+    DevBuf dx((size_t)nx * sizeof(double)), dy((size_t)nxx * sizeof(double));
+    if (nx) DSPMI_HIP_OR_DIE(hipMemcpy(dx.p, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
+    if (order == DESCENDING)
+        DSPMI_OR_DIE(dspmi_fir_exec_f64_desc(plan, dy.as<double>(), nxx, nxx, dx.as<double>(), nx, nx, 1, flags, nullptr));
+    else
+        DSPMI_OR_DIE(dspmi_fir_exec_f64(plan, dy.as<double>(), nxx, nxx, dx.as<double>(), nx, nx, 1, nullptr, 0, flags,
+                                        nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(y, dy.p, (size_t)nxx * sizeof(double), hipMemcpyDeviceToHost));
+    DSPMI_OR_DIE(dspmi_fir_destroy(plan));
+}
+
+std::mutex g_fir_mutex;
+std::vector<double> g_fir_taps = {  // alsa/main.c:389-407
+    -0.131625603115805, 0.103820148451119, 0.096541374482813, 0.102280926834003,
+    0.113689768997426,  0.125850624234278, 0.135740574367069, 0.141133806318268,
+    0.141133806318268,  0.135740574367069, 0.125850624234278, 0.113689768997426,
+    0.102280926834003,  0.096541374482813, 0.103820148451119, -0.131625603115805};
+
+void run_c2c(double (*in)[2], unsigned nx, double (*out)[2], int sign)
+{
+    if (nx == 0) return;
+    dspmi_fft_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fft_create(&plan, nx, DSPMI_F64, -1));
+    const size_t bytes = (size_t)nx * 2 * sizeof(double);
+    DevBuf din(bytes), dout(bytes);
+    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, in, bytes, hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_c2c(plan, din.p, dout.p, 1, sign, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+}
+
+}  // namespace
+
+extern "C" {
+
+void dsp_conv0(const double *x, unsigned int nx, const double *h, unsigned int nh, double *y)
+{
+    // conv0 adds x[i]*h[k-i] into y[k] for ascending i, i.e. descending tap index
+    run_fir(y, nx, x, nx, h, nh, 0, DESCENDING);
+}
+
+void dsp_conv1(const double *x, unsigned int nx, const double *h, unsigned int nh, double *y)
+{
+    // min(i, nh) taps: the j == i term, the only one that reads x[0], never enters
+    run_fir(y, nx, x, nx, h, nh, DSPMI_FIR_DROP_FIRST, ASCENDING);
+}
+
+void dsp_convolve(double *xx, unsigned int nxx, const double *x, unsigned int nx, const double *h, unsigned int nh)
+{
+    run_fir(xx, nxx, x, nx, h, nh, 0, ASCENDING);
+}
+
+void dsp_convolve_alloc(double **xx, unsigned int *nxx, const double *x, unsigned int nx, const double *h,
+                        unsigned int nh)
+{
+    *nxx = nx + nh;
+    *xx = static_cast<double *>(malloc((size_t)*nxx * sizeof(double)));  // the caller free()s it
+    if (!*xx) {
+        fprintf(stderr, "libdspmi: dsp_convolve_alloc: out of host memory\n");
+        abort();
+    }
+    run_fir(*xx, *nxx, x, nx, h, nh, 0, ASCENDING);
+}
+
+void dsp_fir_set_taps(const double *h, unsigned int nh)
+{
+    std::lock_guard<std::mutex> lock(g_fir_mutex);
+    g_fir_taps.assign(h, h + nh);
+}
+
+void dsp_fir(double **xx, unsigned int *nxx, const double *x, unsigned int nx)
+{
+    std::vector<double> taps;
+    {
+        std::lock_guard<std::mutex> lock(g_fir_mutex);
+        taps = g_fir_taps;
+    }
+    dsp_convolve_alloc(xx, nxx, x, nx, taps.data(), (unsigned)taps.size());
+}
+
+void dsp_dft(double (*in)[2], unsigned int nx, double (*out)[2]) { run_c2c(in, nx, out, DSPMI_FORWARD); }
+
+void dsp_idft(double (*in)[2], unsigned int nx, double (*out)[2]) { run_c2c(in, nx, out, DSPMI_BACKWARD); }
+
+void dsp_fft_r2c(double *xx, const double *x, unsigned int n)
+{
+    if (n == 0) return;
+    dspmi_fft_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fft_create(&plan, n, DSPMI_F64, -1));
+    const unsigned nbin = n / 2 + 1;
+    DevBuf din((size_t)n * sizeof(double)), dout((size_t)nbin * 2 * sizeof(double));
+    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_r2c(plan, din.p, dout.p, 1, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dout.p, (size_t)nbin * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+}
+
+void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx)
+{
+    if (nx < 2) return;
+    dspmi_fft_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fft_create(&plan, nx, DSPMI_F64, -1));
+    const size_t bytes = (size_t)nx * 2 * sizeof(double);
+    DevBuf din(bytes), dout(bytes), dmag((size_t)(nx / 2) * sizeof(double));
+    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, x, bytes, hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_c2c(plan, din.p, dout.p, 1, DSPMI_FORWARD, nullptr));
+    DSPMI_OR_DIE(dspmi::ps_abs_f64(dout.p, dmag.as<double>(), nx / 2, (double)nx, 1, nx, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dmag.p, (size_t)(nx / 2) * sizeof(double), hipMemcpyDeviceToHost));
+    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+}
+
+void dsp_filter(double *xx, const double *x, unsigned int n, const double *coeffs)
+{
+    if (n == 0) return;
+    dspmi_fft_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fft_create(&plan, n, DSPMI_F64, -1));
+    const unsigned nbin = n / 2 + 1;
+    DevBuf dx((size_t)n * sizeof(double)), dbins((size_t)nbin * 2 * sizeof(double)), dg((size_t)nbin * sizeof(double));
+    DSPMI_HIP_OR_DIE(hipMemcpy(dx.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    DSPMI_HIP_OR_DIE(hipMemcpy(dg.p, coeffs, (size_t)nbin * sizeof(double), hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_r2c(plan, dx.p, dbins.p, 1, nullptr));
+    DSPMI_OR_DIE(dspmi::bin_gain_f64(dbins.p, dg.as<double>(), nbin, 1, 256, nullptr));
+    DSPMI_OR_DIE(dspmi_fft_exec_c2r(plan, dbins.p, dx.p, 1, nullptr));
+    DSPMI_OR_DIE(dspmi::scale_f64(dx.as<double>(), (double)n, n, 256, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dx.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+"""ctypes bindings for libdspmi.so.
+
+Two groups, mirroring include/dspmi.h:
+  * FirPlan / FftPlan: the device-resident batched API, driven with torch CUDA
+    tensors (only their data_ptr() and the current stream cross the boundary);
+  * conv0, conv1, convolve, fir, dft, idft, fft_r2c, fft_mag, filter: the
+    reference's host routines (same names, argument meaning and order as the C
+    code they replace), taking and returning numpy float64 arrays.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+FORWARD, BACKWARD = -1, +1
+F32, F64 = 0, 1
+FIR_DROP_FIRST = 1
+
+
+class DspmiError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdspmi.so")
+
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+_u = C.c_uint
+_sz = C.c_size_t
+
+_SIGS = {
+    "dspmi_last_error": (C.c_char_p, []),
+    "dspmi_abi_version": (C.c_int, []),
+    "dspmi_device_count": (C.c_int, []),
+    "dspmi_fir_create_f32": (C.c_int, [C.POINTER(_vp), _fp, _u, C.c_int]),
+    "dspmi_fir_create_f64": (C.c_int, [C.POINTER(_vp), _dp, _u, C.c_int]),
+    "dspmi_fir_destroy": (C.c_int, [_vp]),
+    "dspmi_fir_exec_f32": (C.c_int, [_vp, _vp, _sz, _u, _vp, _sz, _u, _u, _vp, _sz, _u, _vp]),
+    "dspmi_fir_exec_f64": (C.c_int, [_vp, _vp, _sz, _u, _vp, _sz, _u, _u, _vp, _sz, _u, _vp]),
+    "dspmi_fir_variant": (C.c_char_p, [_vp]),
+    "dspmi_fft_create": (C.c_int, [C.POINTER(_vp), _u, C.c_int, C.c_int]),
+    "dspmi_fft_destroy": (C.c_int, [_vp]),
+    "dspmi_fft_exec_c2c": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp]),
+    "dspmi_fft_exec_r2c": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "dspmi_fft_exec_c2r": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "dspmi_fft_variant": (C.c_char_p, [_vp]),
+    "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
+    "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
+    "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),
+    "dsp_convolve_alloc": (None, [C.POINTER(_dp), C.POINTER(_u), _dp, _u, _dp, _u]),
+    "dsp_fir_set_taps": (None, [_dp, _u]),
+    "dsp_fir": (None, [C.POINTER(_dp), C.POINTER(_u), _dp, _u]),
+    "dsp_dft": (None, [_dp, _u, _dp]),
+    "dsp_idft": (None, [_dp, _u, _dp]),
+    "dsp_fft_r2c": (None, [_dp, _dp, _u]),
+    "dsp_fft_mag": (None, [_dp, _u, _dp]),
+    "dsp_filter": (None, [_dp, _dp, _u, _dp]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/dspmi.h declares."""
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load libdspmi.so (once).  Raises if it is missing: nothing here falls back to the CPU."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise DspmiError("%s not found: build it with `python -m dsp_amd.build` "
+                             "(or __graft_entry__.build())" % path)
+        L = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DspmiError("%s failed (%d): %s" % (what, rc, lib().dspmi_last_error().decode()))
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------------------
+# device-resident batched API
+# ---------------------------------------------------------------------------
+
+class FirPlan:
+    """Taps resident on the device; exec() runs the batched FIR on torch CUDA tensors."""
+
+    def __init__(self, taps, dtype="f32", device=-1):
+        self.f64 = dtype in ("f64", np.float64)
+        self.nh = len(taps)
+        self._h = C.c_void_p()
+        if self.f64:
+            t = np.ascontiguousarray(taps, dtype=np.float64)
+            _check(lib().dspmi_fir_create_f64(C.byref(self._h), t.ctypes.data_as(_dp), self.nh, device), "fir_create_f64")
+        else:
+            t = np.ascontiguousarray(taps, dtype=np.float32)
+            _check(lib().dspmi_fir_create_f32(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, device), "fir_create_f32")
+
+    @property
+    def variant(self):
+        return lib().dspmi_fir_variant(self._h).decode()
+
+    def exec(self, x, nxx=None, y=None, hist=None, flags=0):
+        """x: [nchan, nx] CUDA tensor (last dim contiguous).  Returns y [nchan, nxx]."""
+        import torch
+        want = torch.float64 if self.f64 else torch.float32
+        assert x.is_cuda and x.dtype == want and x.dim() == 2 and x.stride(1) == 1
+        nchan, nx = x.shape
+        if nxx is None:
+            nxx = nx
+        if y is None:
+            y = torch.empty((nchan, nxx), dtype=want, device=x.device)
+        assert y.is_cuda and y.dtype == want and y.shape == (nchan, nxx) and y.stride(1) == 1
+        hp, hs = None, 0
+        if hist is not None:
+            assert hist.is_cuda and hist.dtype == want and hist.shape == (nchan, self.nh - 1) and hist.stride(1) == 1
+            hp, hs = hist.data_ptr(), hist.stride(0) if nchan > 1 else self.nh - 1
+        fn = lib().dspmi_fir_exec_f64 if self.f64 else lib().dspmi_fir_exec_f32
+        _check(fn(self._h, y.data_ptr(), y.stride(0) if nchan > 1 else nxx, nxx,
+                  x.data_ptr(), x.stride(0) if nchan > 1 else nx, nx, nchan, hp, hs, flags, _stream()), "fir_exec")
+        return y
+
+    def close(self):
+        if self._h:
+            lib().dspmi_fir_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FftPlan:
+    """Twiddles + kernel choice for one length; exec on torch CUDA complex/real tensors."""
+
+    def __init__(self, n, dtype="f32", device=-1):
+        self.f64 = dtype in ("f64", np.float64)
+        self.n = n
+        self._h = C.c_void_p()
+        _check(lib().dspmi_fft_create(C.byref(self._h), n, F64 if self.f64 else F32, device), "fft_create")
+
+    @property
+    def variant(self):
+        return lib().dspmi_fft_variant(self._h).decode()
+
+    def _types(self):
+        import torch
+        return (torch.complex128, torch.float64) if self.f64 else (torch.complex64, torch.float32)
+
+    def c2c(self, x, sign=FORWARD, out=None):
+        """x: [batch, n] complex CUDA tensor, contiguous.  Unnormalised both ways."""
+        import torch
+        ct, _ = self._types()
+        assert x.is_cuda and x.dtype == ct and x.is_contiguous() and x.shape[-1] == self.n
+        if out is None:
+            out = torch.empty_like(x)
+        assert out.is_cuda and out.dtype == ct and out.is_contiguous() and out.shape == x.shape
+        batch = x.numel() // self.n
+        _check(lib().dspmi_fft_exec_c2c(self._h, x.data_ptr(), out.data_ptr(), batch, sign, _stream()), "fft_exec_c2c")
+        return out
+
+    def r2c(self, x, out=None):
+        import torch
+        ct, rt = self._types()
+        assert x.is_cuda and x.dtype == rt and x.is_contiguous() and x.shape[-1] == self.n
+        batch = x.numel() // self.n
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (self.n // 2 + 1,), dtype=ct, device=x.device)
+        _check(lib().dspmi_fft_exec_r2c(self._h, x.data_ptr(), out.data_ptr(), batch, _stream()), "fft_exec_r2c")
+        return out
+
+    def c2r(self, x, out=None):
+        import torch
+        ct, rt = self._types()
+        assert x.is_cuda and x.dtype == ct and x.is_contiguous() and x.shape[-1] == self.n // 2 + 1
+        batch = x.numel() // (self.n // 2 + 1)
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (self.n,), dtype=rt, device=x.device)
+        _check(lib().dspmi_fft_exec_c2r(self._h, x.data_ptr(), out.data_ptr(), batch, _stream()), "fft_exec_c2r")
+        return out
+
+    def close(self):
+        if self._h:
+            lib().dspmi_fft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# host drop-in routines (numpy float64 in / out), named as in the reference
+# ---------------------------------------------------------------------------
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def conv0(x, h):
+    """convolution/main.c:15-33 -- y[nx]."""
+    x, xp = _d(x); h, hp = _d(h)
+    y = np.empty(len(x))
+    lib().dsp_conv0(xp, len(x), hp, len(h), y.ctypes.data_as(_dp))
+    return y
+
+
+def conv1(x, h):
+    """convolution/main.c:36-53 -- y[nx], bug-compatible."""
+    x, xp = _d(x); h, hp = _d(h)
+    y = np.empty(len(x))
+    lib().dsp_conv1(xp, len(x), hp, len(h), y.ctypes.data_as(_dp))
+    return y
+
+
+def convolve(x, h, nxx):
+    """fir/src/main.c:258-280 -- caller chooses the output length nxx."""
+    x, xp = _d(x); h, hp = _d(h)
+    xx = np.empty(nxx)
+    lib().dsp_convolve(xx.ctypes.data_as(_dp), nxx, xp, len(x), hp, len(h))
+    return xx
+
+
+def _take(ptr, n):
+    """Copy a malloc'd double buffer into numpy and free() it, as the reference's caller does."""
+    out = np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+def convolve_alloc(x, h):
+    """fft/src/main.c:180-205 -- library-allocated result of nx+nh doubles."""
+    x, xp = _d(x); h, hp = _d(h)
+    ptr, n = _dp(), _u()
+    lib().dsp_convolve_alloc(C.byref(ptr), C.byref(n), xp, len(x), hp, len(h))
+    return _take(ptr, n.value)
+
+
+def fir_set_taps(h):
+    h, hp = _d(h)
+    lib().dsp_fir_set_taps(hp, len(h))
+
+
+def fir(x):
+    """fft/src/main.c:207-244 -- convolve with the bound tap table."""
+    x, xp = _d(x)
+    ptr, n = _dp(), _u()
+    lib().dsp_fir(C.byref(ptr), C.byref(n), xp, len(x))
+    return _take(ptr, n.value)
+
+
+def _c(z):
+    z = np.ascontiguousarray(z, dtype=np.complex128)
+    return z, z.view(np.float64).ctypes.data_as(_dp)
+
+
+def dft(z):
+    """fftc/main.c:31-36."""
+    z, zp = _c(z)
+    out = np.empty(len(z), dtype=np.complex128)
+    lib().dsp_dft(zp, len(z), out.view(np.float64).ctypes.data_as(_dp))
+    return out
+
+
+def idft(z):
+    """fftc/main.c:38-43 (unnormalised)."""
+    z, zp = _c(z)
+    out = np.empty(len(z), dtype=np.complex128)
+    lib().dsp_idft(zp, len(z), out.view(np.float64).ctypes.data_as(_dp))
+    return out
+
+
+def fft_r2c(x):
+    """fft/src/main.c:146-168 -- bins 0..n/2."""
+    x, xp = _d(x)
+    out = np.empty(len(x) // 2 + 1, dtype=np.complex128)
+    lib().dsp_fft_r2c(out.view(np.float64).ctypes.data_as(_dp), xp, len(x))
+    return out
+
+
+def fft_mag(z):
+    """fir/src/main.c:229-255 -- 2|X|/nx over nx/2 bins."""
+    z, zp = _c(z)
+    out = np.empty(len(z) // 2)
+    lib().dsp_fft_mag(zp, len(z), out.ctypes.data_as(_dp))
+    return out
+
+
+def filter(x, coeffs):  # noqa: A001 - the reference's name
+    """util/filter/filter.c:73-105."""
+    x, xp = _d(x); coeffs, cp = _d(coeffs)
+    assert len(coeffs) == len(x) // 2 + 1
+    xx = np.empty(len(x))
+    lib().dsp_filter(xx.ctypes.data_as(_dp), xp, len(x), cp)
+    return xx

@@ -1,0 +1,179 @@
+/*
+ * dspmi.h -- C ABI of libdspmi.so, the MI355X (gfx950) implementation of the
+ * texane/dsp FIR / convolution / FFT hot path.
+ *
+ * Two levels:
+ *
+ *  1. Device-resident batched API (dspmi_*): plain pointers to DEVICE memory,
+ *     sizes, an opaque plan handle and a HIP stream passed as void*.  Returns
+ *     0 on success or a negative errno-style code (the reference's own
+ *     convention for fallible calls, util/common/csv.c:147-216,
+ *     util/filter/filter.c get_cmdline_info: -1 on error); dspmi_last_error()
+ *     gives the text.  This is the measured path.
+ *
+ *  2. Host drop-in wrappers (dsp_*): the exact C signatures of the reference's
+ *     static compute routines, taking caller-owned HOST double buffers,
+ *     blocking until the result is back in host memory.  The reference's
+ *     routines return void and check nothing; these do the same on success and
+ *     print the failing HIP call to stderr and abort() on any device error --
+ *     there is no CPU fallback anywhere in the library.  They compute in
+ *     double precision on the device.  include/dsp_dropin.h maps the
+ *     reference's unprefixed names (conv0, convolve, fir, dft, ...) onto them.
+ *
+ * No C++ or torch types appear in any signature.
+ */
+#ifndef DSPMI_H_INCLUDED
+#define DSPMI_H_INCLUDED
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (negative errno values) -------------------------------- */
+#define DSPMI_OK       0
+#define DSPMI_EIO     (-5)   /* a HIP runtime call failed */
+#define DSPMI_ENOMEM  (-12)  /* host or device allocation failed */
+#define DSPMI_EINVAL  (-22)  /* bad argument */
+#define DSPMI_ENOSYS  (-38)  /* size / mode not supported by any kernel */
+
+/* Text of the calling thread's most recent error ("" if none). */
+const char *dspmi_last_error(void);
+
+/* ABI version of the loaded library (this header: 1). */
+int dspmi_abi_version(void);
+
+/* Number of visible HIP devices, or a negative error code. */
+int dspmi_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* FIR / direct convolution                                                  */
+/* ------------------------------------------------------------------------ */
+
+/* A FIR plan holds the taps on one device (uploaded once, zero-padded to the
+ * kernel's tap-block size), so tap staging is off the timed path -- the role
+ * the compiled-in tap table plays in the reference (fft/src/main.c:213-243,
+ * alsa/main.c:389-407). */
+typedef struct dspmi_fir_plan *dspmi_fir_t;
+
+/* taps: nh HOST values, h[0] first.  device < 0 means the current device. */
+int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device);
+int dspmi_fir_create_f64(dspmi_fir_t *plan, const double *taps, unsigned nh, int device);
+int dspmi_fir_destroy(dspmi_fir_t plan);
+
+/* flags for dspmi_fir_exec_* */
+#define DSPMI_FIR_DROP_FIRST 1u /* conv1's off-by-one (convolution/main.c:48):
+                                   x[0] of every channel never contributes */
+
+/*
+ * Batched gather convolution, one independent channel per row:
+ *
+ *   y[c][i] = sum_{j < nh, 0 <= i-j < nx} h[j] * x[c][i-j],   0 <= i < nxx
+ *
+ * which is `convolve` of fir/src/main.c:258-280 / alsa/main.c:494-516 (any
+ * nxx), the allocating `convolve` of fft/src/main.c:180-205 (nxx = nx+nh) and
+ * conv0 of convolution/main.c:15-33 (nxx = nx).  Taps before x[c][0] read the
+ * zero history the reference assumes, or, when hist != NULL, the nh-1 samples
+ * hist[c][0..nh-2] that preceded x[c][0] (oldest first; hist_stride elements
+ * between channels) -- the carried state a streaming caller needs and the
+ * reference lacks (alsa/main.c:530 restarts from zero every period).
+ *
+ * x, y, hist: DEVICE pointers; x_stride / y_stride: elements between
+ * consecutive channels (>= nx / >= nxx).  y must not overlap x.
+ * stream: a hipStream_t (NULL = the default stream).  Asynchronous.
+ */
+int dspmi_fir_exec_f32(dspmi_fir_t plan, float *y, size_t y_stride, unsigned nxx,
+                       const float *x, size_t x_stride, unsigned nx,
+                       unsigned nchan, const float *hist, size_t hist_stride,
+                       unsigned flags, void *stream);
+int dspmi_fir_exec_f64(dspmi_fir_t plan, double *y, size_t y_stride, unsigned nxx,
+                       const double *x, size_t x_stride, unsigned nx,
+                       unsigned nchan, const double *hist, size_t hist_stride,
+                       unsigned flags, void *stream);
+
+/* Name of the kernel variant the plan dispatches to (for profiles / logs). */
+const char *dspmi_fir_variant(dspmi_fir_t plan);
+
+/* ------------------------------------------------------------------------ */
+/* FFT                                                                       */
+/* ------------------------------------------------------------------------ */
+
+/* Interleaved re,im -- the layout of FFTW's fftw_complex that every
+ * reference FFT call site uses (fftc/main.c:140-144). */
+typedef struct { float re, im; } dspmi_c32;
+typedef struct { double re, im; } dspmi_c64;
+
+#define DSPMI_FORWARD  (-1) /* FFTW_FORWARD:  exponent -2*pi*i*n*k/N */
+#define DSPMI_BACKWARD (+1) /* FFTW_BACKWARD: exponent +, unnormalised */
+
+#define DSPMI_F32 0
+#define DSPMI_F64 1
+
+/* An FFT plan holds the twiddle table (computed in double on the host, rounded
+ * once) and the kernel choice for one transform length on one device; it is
+ * the counterpart of fftw_plan_dft_1d / _r2c_1d / _c2r_1d + fftw_destroy_plan
+ * (fftc/main.c:33-35, fft/src/main.c:156-166, util/filter/filter.c:86-103). */
+typedef struct dspmi_fft_plan *dspmi_fft_t;
+
+/* n: transform length (complex points, or real samples for r2c/c2r).
+ * Returns DSPMI_ENOSYS for a length no kernel covers. */
+int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device);
+int dspmi_fft_destroy(dspmi_fft_t plan);
+
+/* batch independent transforms, frame f at in + f*n / out + f*n (elements of
+ * dspmi_c32 or dspmi_c64 according to the plan's precision).  Unnormalised in
+ * both directions, natural order in and out.  in == out is allowed. */
+int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
+                       int sign, void *stream);
+
+/* Real-input forward transform: in [batch][n] reals, out [batch][n/2+1]
+ * complex (bins 0..n/2), the fftw_plan_dft_r2c_1d contract
+ * (fft/src/main.c:155-158).  n must be even. */
+int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
+                       void *stream);
+
+/* Backward transform of a Hermitian half spectrum: in [batch][n/2+1] complex,
+ * out [batch][n] reals, unnormalised (fftw_plan_dft_c2r_1d,
+ * util/filter/filter.c:100-101).  The input is left intact. */
+int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch,
+                       void *stream);
+
+const char *dspmi_fft_variant(dspmi_fft_t plan);
+
+/* ------------------------------------------------------------------------ */
+/* Host drop-in wrappers (reference signatures; host double buffers)         */
+/* ------------------------------------------------------------------------ */
+
+/* convolution/main.c:15-33 */
+void dsp_conv0(const double *x, unsigned int nx, const double *h, unsigned int nh,
+               double *y);
+/* convolution/main.c:36-53 (bug-compatible: drops the j == i term) */
+void dsp_conv1(const double *x, unsigned int nx, const double *h, unsigned int nh,
+               double *y);
+/* fir/src/main.c:258-280 == alsa/main.c:494-516 (caller-owned xx[nxx]) */
+void dsp_convolve(double *xx, unsigned int nxx, const double *x, unsigned int nx,
+                  const double *h, unsigned int nh);
+/* fft/src/main.c:180-205: *xx = malloc((nx+nh) doubles), the caller free()s it */
+void dsp_convolve_alloc(double **xx, unsigned int *nxx, const double *x,
+                        unsigned int nx, const double *h, unsigned int nh);
+/* fft/src/main.c:207-244: `fir` with its compiled-in table; the table is bound
+ * here at run time instead (default: the 16 taps of alsa/main.c:389-407). */
+void dsp_fir_set_taps(const double *h, unsigned int nh);
+void dsp_fir(double **xx, unsigned int *nxx, const double *x, unsigned int nx);
+
+/* fftc/main.c:31-43; in/out are fftw_complex arrays (double[2]) */
+void dsp_dft(double (*in)[2], unsigned int nx, double (*out)[2]);
+void dsp_idft(double (*in)[2], unsigned int nx, double (*out)[2]);
+/* fft/src/main.c:146-168 == util/fft/fft.c:99-121: xx[2*(n/2+1)] <- r2c(x[n]) */
+void dsp_fft_r2c(double *xx, const double *x, unsigned int n);
+/* fir/src/main.c:229-255: xx[i] = 2|X[i]|/nx for i < nx/2 */
+void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx);
+/* util/filter/filter.c:73-105 */
+void dsp_filter(double *xx, const double *x, unsigned int n, const double *coeffs);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* DSPMI_H_INCLUDED */

@@ -1,0 +1,50 @@
+"""The C-ABI library loads without a GPU and exports what include/dspmi.h declares."""
+import ctypes
+import os
+import re
+
+import dsp_amd
+import importlib
+
+L = importlib.import_module('dsp_amd.lib')
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dspmi?_[a-z0-9_]+|dsp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = dsp_amd.lib()
+    names = _declared("dspmi.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    # and the Python binding table covers exactly the header
+    assert sorted(L.exported_symbols()) == names
+
+
+def test_abi_version_and_error_channel():
+    lib = dsp_amd.lib()
+    assert lib.dspmi_abi_version() == 1
+    h = ctypes.c_void_p()
+    # argument errors are reported without touching a device
+    rc = lib.dspmi_fir_create_f32(ctypes.byref(h), None, 0, -1)
+    assert rc == -22 and b"fir_create" in lib.dspmi_last_error()
+    rc = lib.dspmi_fft_create(ctypes.byref(h), 0, 0, -1)
+    assert rc == -22
+    rc = lib.dspmi_fft_create(ctypes.byref(h), 1000, 7, -1)
+    assert rc == -22
+
+
+def test_no_oracle_or_cpu_path_in_the_product():
+    """The shipped package must not import the checker."""
+    for root, _, files in os.walk(os.path.join(ROOT, "dsp_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+                assert "liboracle" not in txt and "dsp_oracle" not in txt, f

@@ -1,0 +1,131 @@
+"""Parity of the HIP FFT path against the oracle, through the C ABI.
+
+"Parity unpinned": the reference's transforms are FFTW3's, which is not
+available; the checker is the oracle's long-double DFT (committed vectors) and
+its double radix-2.  f32 tolerance: relative L2 <= 1e-5 per frame.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dsp_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_FFT = 1e-5   # f32, relative L2 per frame
+TOL_F64 = 1e-13  # double wrappers, relative L2
+
+
+def rel_l2(got, want):
+    den = np.linalg.norm(want)
+    return np.linalg.norm(got - want) / den if den > 0 else np.linalg.norm(got)
+
+
+POW2 = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384]
+
+
+@pytest.mark.parametrize("n", POW2)
+def test_c2c_f32_against_oracle(n):
+    rng = np.random.default_rng(n)
+    batch = 7 if n <= 4096 else 3
+    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
+    plan = dsp_amd.FftPlan(n, "f32")
+    zd = torch.from_numpy(z).cuda()
+    fwd = plan.c2c(zd, dsp_amd.FORWARD).cpu().numpy()
+    bwd = plan.c2c(zd, dsp_amd.BACKWARD).cpu().numpy()
+    method = "direct" if n <= 2048 else "radix2"
+    for f in range(batch):
+        zz = z[f].astype(np.complex128)
+        assert rel_l2(fwd[f], oracle.dft(zz, -1, method)) <= TOL_FFT, (plan.variant, f)
+        assert rel_l2(bwd[f], oracle.dft(zz, +1, method)) <= TOL_FFT, (plan.variant, f)
+
+
+@pytest.mark.parametrize("n", [8, 64, 1024, 4096])
+def test_c2c_golden_vectors(golden_dir, n):
+    g = np.load(os.path.join(golden_dir, "fft_cases.npz"))
+    z = g["in_%d" % n]
+    plan = dsp_amd.FftPlan(n, "f32")
+    zd = torch.from_numpy(z.astype(np.complex64)[None, :]).cuda()
+    assert rel_l2(plan.c2c(zd, dsp_amd.FORWARD).cpu().numpy()[0], g["fwd_%d" % n]) <= TOL_FFT
+    assert rel_l2(plan.c2c(zd, dsp_amd.BACKWARD).cpu().numpy()[0], g["bwd_%d" % n]) <= TOL_FFT
+    # double wrappers
+    assert rel_l2(dsp_amd.dft(z), g["fwd_%d" % n]) <= TOL_F64
+    assert rel_l2(dsp_amd.idft(z), g["bwd_%d" % n]) <= TOL_F64
+
+
+def test_c2c_in_place_and_odd_batches():
+    n = 1024
+    plan = dsp_amd.FftPlan(n, "f32")
+    for batch in (1, 3, 4, 5, 1000, 4097):
+        g = torch.Generator(device="cuda").manual_seed(batch)
+        z = torch.view_as_complex(torch.rand((batch, n, 2), device="cuda", generator=g) * 2 - 1)
+        want = plan.c2c(z)
+        buf = z.clone()
+        plan.c2c(buf, out=buf)
+        assert torch.equal(buf, want)
+        ref = torch.fft.fft(z.to(torch.complex128))
+        err = ((want.to(torch.complex128) - ref).abs().pow(2).sum(1).sqrt() / ref.abs().pow(2).sum(1).sqrt()).max()
+        assert err.item() <= TOL_FFT, batch
+
+
+def test_known_answers():
+    n = 1024
+    plan = dsp_amd.FftPlan(n, "f32")
+    x = torch.zeros((3, n), dtype=torch.complex64, device="cuda")
+    x[0, 0] = 1                                     # impulse -> all ones
+    x[1, :] = 1                                     # constant -> n at bin 0
+    k = 37
+    t = torch.arange(n, device="cuda")
+    x[2] = torch.exp(2j * np.pi * k * t / n).to(torch.complex64) * 0.5   # single bin tone
+    y = plan.c2c(x).cpu().numpy()
+    assert np.allclose(y[0], 1.0, atol=1e-6)
+    assert abs(y[1, 0] - n) < 1e-3 and np.abs(y[1, 1:]).max() < 1e-3
+    assert abs(y[2, k] - 0.5 * n) < 1e-2 and np.abs(np.delete(y[2], k)).max() < 2e-2
+
+
+def test_round_trip_and_parseval_at_scale():
+    """Properties that do not need the oracle, on a batch the oracle could not sweep."""
+    n, batch = 1024, 1 << 16
+    plan = dsp_amd.FftPlan(n, "f32")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    z = torch.view_as_complex(torch.rand((batch, n, 2), device="cuda", generator=g) * 2 - 1)
+    y = plan.c2c(z, dsp_amd.FORWARD)
+    back = plan.c2c(y, dsp_amd.BACKWARD) / n     # c2c backward is unnormalised (fftc/main.c:164 divides by nx)
+    err = ((back - z).abs().pow(2).sum(1).sqrt() / z.abs().pow(2).sum(1).sqrt()).max()
+    assert err.item() <= TOL_FFT
+    e_t = z.abs().double().pow(2).sum(1)
+    e_f = y.abs().double().pow(2).sum(1) / n
+    assert ((e_t - e_f).abs() / e_t).max().item() < 1e-5
+    # spot frames against the oracle
+    for f in (0, batch // 2, batch - 1):
+        assert rel_l2(y[f].cpu().numpy(), oracle.dft(z[f].cpu().numpy().astype(np.complex128), -1, "direct")) <= TOL_FFT
+
+
+@pytest.mark.parametrize("n", [4, 16, 1024, 4096, 8192])
+def test_r2c_c2r_f32(n):
+    rng = np.random.default_rng(n + 1)
+    x = rng.uniform(-1, 1, (5, n)).astype(np.float32)
+    plan = dsp_amd.FftPlan(n, "f32")
+    xd = torch.from_numpy(x).cuda()
+    bins = plan.r2c(xd)
+    got = bins.cpu().numpy()
+    for f in range(5):
+        assert rel_l2(got[f], oracle.fft_r2c(x[f].astype(np.float64))) <= TOL_FFT
+    back = plan.c2r(bins).cpu().numpy() / n
+    for f in range(5):
+        assert rel_l2(back[f], x[f]) <= TOL_FFT
+        want = oracle.fft_c2r(got[f].astype(np.complex128), n)
+        assert rel_l2(back[f] * n, want) <= TOL_FFT
+
+
+def test_double_wrappers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "fft_cases.npz"))
+    x = g["filter_x"]
+    assert rel_l2(dsp_amd.fft_r2c(x), g["r2c_4096"]) <= TOL_F64
+    assert rel_l2(dsp_amd.filter(x, g["filter_gains"]), g["filter_y"]) <= TOL_F64
+    assert rel_l2(dsp_amd.filter(x, np.ones(2049)), x) <= TOL_F64
+    z = g["in_1024"]
+    assert rel_l2(dsp_amd.fft_mag(z), oracle.ps_abs(g["fwd_1024"])) <= TOL_F64

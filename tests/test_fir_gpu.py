@@ -1,0 +1,178 @@
+"""Parity of the HIP FIR / convolution path against the oracle, through the C ABI.
+
+f32 device API: relative L2 error <= 1e-6 per output block (each channel row),
+against the oracle's double accumulation of the same f32 inputs.  The kernel
+sums with f32 FMAs in ascending tap order; the reference sums in double.
+f64 host wrappers: bit-exact against the oracle / the reference's own vectors.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dsp_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_FIR = 1e-6  # relative L2 per output block, f32 vs the double oracle
+
+
+def rel_l2(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    den = np.linalg.norm(want)
+    return np.linalg.norm(got - want) / den if den > 0 else np.linalg.norm(got)
+
+
+def run_f32(x, h, nxx, hist=None, flags=0):
+    plan = dsp_amd.FirPlan(h, "f32")
+    xd = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    hd = None if hist is None else torch.from_numpy(np.ascontiguousarray(hist, dtype=np.float32)).cuda()
+    y = plan.exec(xd, nxx, hist=hd, flags=flags)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), plan.variant
+
+
+# ---- host wrappers (double): exact ---------------------------------------------
+
+def test_kat9_wrappers(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "conv_kat9.json")))
+    x, h = np.array(kat["x"]), np.array(kat["h"])
+    assert np.array_equal(dsp_amd.conv0(x, h), np.array(kat["y0"]))
+    assert np.array_equal(dsp_amd.conv1(x, h), np.array(kat["y1"]))
+    assert np.allclose(dsp_amd.conv0(x, h), kat["y0_printed"], atol=5e-7, rtol=0)
+    assert np.allclose(dsp_amd.conv1(x, h), kat["y1_printed"], atol=5e-7, rtol=0)
+
+
+def test_wrappers_bit_exact_against_reference_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "conv_ref_cases.npz"))
+    for i in range(9):
+        x, h = g["x%d" % i], g["h%d" % i]
+        assert np.array_equal(dsp_amd.conv0(x, h), g["y0_%d" % i]), i
+        assert np.array_equal(dsp_amd.conv1(x, h), g["y1_%d" % i]), i
+        full = oracle.convolve(x, h)
+        assert np.array_equal(dsp_amd.convolve_alloc(x, h), full), i
+        assert np.array_equal(dsp_amd.convolve(x, h, len(x)), full[:len(x)]), i
+        assert np.array_equal(dsp_amd.convolve(x, h, len(x) + 2 * len(h)), oracle.convolve(x, h, len(x) + 2 * len(h))), i
+
+
+def test_fir_wrapper_tone_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tone_fir.npz"))
+    got = dsp_amd.fir(g["tone"])  # default table: alsa/main.c:389-407
+    assert np.array_equal(got, g["y16"])
+    dsp_amd.fir_set_taps(g["taps21"])
+    try:
+        assert np.array_equal(dsp_amd.fir(g["tone"]), g["y21"])
+    finally:
+        dsp_amd.fir_set_taps(g["taps16"])
+
+
+def test_wrapper_long_kernel_multi_segment():
+    """More taps than one LDS staging round holds (fir/src/main.c:324 convolves with a
+    964-point kernel; go beyond the 2048-tap segment too)."""
+    rng = np.random.default_rng(5)
+    for nx, nh in [(2000, 964), (3000, 2500), (700, 5000)]:
+        x, h = rng.standard_normal(nx), rng.standard_normal(nh)
+        assert np.array_equal(dsp_amd.convolve(x, h, nx), oracle.convolve(x, h, nx))
+        assert np.array_equal(dsp_amd.conv0(x, h), oracle.conv0(x, h))
+
+
+# ---- f32 device API -----------------------------------------------------------------
+
+@pytest.mark.parametrize("nh", [1, 9, 16, 21, 32, 33, 127, 128, 300])
+@pytest.mark.parametrize("nx,nchan", [(1, 1), (100, 3), (4096, 2), (5000, 4), (70000, 2)])
+def test_f32_parity(nh, nx, nchan):
+    rng = np.random.default_rng(nh * 1000 + nx)
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    h = (oracle.windowed_sinc_taps(nh) if nh >= 9 else rng.uniform(-1, 1, nh)).astype(np.float32)
+    for nxx in (nx, nx + nh):
+        got, variant = run_f32(x, h, nxx)
+        want = oracle.fir_batch_f32(x, h, nxx)
+        for c in range(nchan):
+            assert rel_l2(got[c], want[c]) <= TOL_FIR, (variant, nh, nx, nxx, c)
+        if nxx == nx + nh:
+            assert np.all(got[:, -1] == 0)  # the extra element of fft/src/main.c:190
+
+
+def test_f32_reference_taps_and_tone(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tone_fir.npz"))
+    tone = g["tone"].astype(np.float32)[None, :]
+    for taps, key in ((g["taps16"], "y16"), (g["taps21"], "y21")):
+        got, _ = run_f32(tone, taps.astype(np.float32), len(g[key]))
+        assert rel_l2(got[0], oracle.fir_batch_f32(tone, taps.astype(np.float32), len(g[key]))[0]) <= TOL_FIR
+        # and against the double-precision vector itself: input rounding (2^-24) dominates
+        assert rel_l2(got[0], g[key]) <= 5e-7
+
+
+def test_f32_drop_first_is_conv1():
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (3, 777)).astype(np.float32)
+    h = rng.uniform(-1, 1, 19).astype(np.float32)
+    got, _ = run_f32(x, h, 777, flags=dsp_amd.FIR_DROP_FIRST)
+    want = oracle.fir_batch_f32(x, h, 777, drop_first=True)
+    for c in range(3):
+        assert rel_l2(got[c], want[c]) <= TOL_FIR
+        ref = oracle.conv1(x[c].astype(np.float64), h.astype(np.float64))
+        assert rel_l2(got[c], ref) <= TOL_FIR
+
+
+def test_f32_streaming_history_matches_one_block():
+    rng = np.random.default_rng(21)
+    nchan, nh = 5, 127
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (nchan, 3 * 8192)).astype(np.float32)
+    whole = oracle.fir_batch_f32(x, h, x.shape[1])
+    plan = dsp_amd.FirPlan(h, "f32")
+    xd = torch.from_numpy(x).cuda()
+    hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
+    outs = []
+    for k in range(3):
+        chunk = xd[:, k * 8192:(k + 1) * 8192]
+        outs.append(plan.exec(chunk, 8192, hist=hist).cpu().numpy())
+        hist = chunk[:, -(nh - 1):].contiguous()
+    got = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert rel_l2(got[c], whole[c]) <= TOL_FIR
+
+
+def test_f32_strided_rows_and_unaligned_views():
+    rng = np.random.default_rng(2)
+    h = rng.uniform(-1, 1, 16).astype(np.float32)
+    big = torch.from_numpy(rng.uniform(-1, 1, (4, 1000)).astype(np.float32)).cuda()
+    x = big[:, 3:903]  # row stride 1000, start 12 bytes off a 16-byte boundary
+    ybig = torch.zeros((4, 1003), dtype=torch.float32, device="cuda")
+    y = ybig[:, 1:901]
+    plan = dsp_amd.FirPlan(h, "f32")
+    plan.exec(x, 900, y=y)
+    want = oracle.fir_batch_f32(x.cpu().numpy(), h, 900)
+    got = y.cpu().numpy()
+    for c in range(4):
+        assert rel_l2(got[c], want[c]) <= TOL_FIR
+    assert torch.all(ybig[:, 0] == 0) and torch.all(ybig[:, 901:] == 0)  # nothing written outside the rows
+
+
+def test_linearity_and_impulse_at_scale():
+    """Size-independent properties on a block too large for the oracle to sweep."""
+    nh, nchan, nx = 127, 64, 1 << 20
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
+    b = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
+    ya, yb, yab = plan.exec(a), plan.exec(b), plan.exec(a + b)
+    err = (yab - (ya + yb)).double().norm() / yab.double().norm()
+    assert err.item() < 1e-6
+    imp = torch.zeros((2, nx), device="cuda")
+    imp[0, 0] = 1.0
+    imp[1, nx - 200] = 1.0
+    yi = plan.exec(imp).cpu().numpy()
+    assert np.array_equal(yi[0, :nh], h) and not yi[0, nh:].any()
+    assert np.array_equal(yi[1, nx - 200:nx - 200 + nh], h) and not yi[1, :nx - 200].any()
+    # spot rows against the oracle
+    want = oracle.fir_batch_f32(a[:2, :20000].cpu().numpy(), h, 20000)
+    got = ya[:2, :20000].cpu().numpy()
+    for c in range(2):
+        assert rel_l2(got[c], want[c]) <= TOL_FIR
