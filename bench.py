@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Benchmark of the FIR / FFT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload fft1024|fir127|fir16]
+
+One "step" is one pass of the hot path over one batch of synthetic input that
+is already resident in HBM.  The default workload is BASELINE.json configs[1]:
+batched complex f32 FFT, N = 1024, 2^20 frames per GPU (8 GiB in, 8 GiB out).
+With N > 1 ranks (one process per GPU, launched by torch.distributed.run) every
+rank transforms its own 2^20 frames: frames are independent, so the data path
+has no collective ("scaling": "weak"); the only communication is the timing
+barrier and the max-over-ranks reduction.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     : the dominant kernel against the HBM (or FP32 vector) roof, from
+                 HIP events recorded on the launch stream around the timed region
+  cpu_baseline : the oracle's CPU port timed on a bounded sample of the same
+                 workload on this box's host cores (rank 0, N = 1 only)
+  secondary    : short measurements of the two FIR regimes (127 and 16 taps)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import dsp_amd
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir16"])
+    ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
+    ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
+    ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def uniform(shape, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    return torch.rand(shape, device=device, generator=g, dtype=torch.float32) * 2 - 1
+
+
+def timed(fn, steps, warmup, world):
+    """Returns (wall seconds over `steps`, max over ranks; event ms per launch on this rank)."""
+    for _ in range(warmup):
+        fn()
+    barrier(world)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    return dt, e0.elapsed_time(e1) / steps
+
+
+# ---------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------
+
+def make_fft(args, rank):
+    n = 1024
+    z = torch.view_as_complex(uniform((args.frames, n, 2), 0xD5B0 + 2 + rank, "cuda"))
+    out = torch.empty_like(z)
+    plan = dsp_amd.FftPlan(n, "f32")
+    flop_per_frame = 5.0 * n * math.log2(n)     # nominal radix-2 count
+    bytes_per_frame = 2.0 * n * 8               # read once + write once
+    info = dict(kernel=plan.variant, units=args.frames, unit_name="frames", n=n,
+                flop_per_unit=flop_per_frame, bytes_per_unit=bytes_per_frame, bound="hbm",
+                samples_per_unit=n,
+                workload="batched c2c f32 FFT, N=1024, %d frames per GPU, out of place" % args.frames)
+    return (lambda: plan.c2c(z, dsp_amd.FORWARD, out=out)), info, (plan, z, out)
+
+
+def sinc_taps(nh):
+    k = np.arange(nh, dtype=np.float64) - (nh - 1) / 2.0
+    h = np.sinc(2.0 * 6000.0 / 48000.0 * k) * (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(nh) / (nh - 1)))
+    return (h / h.sum()).astype(np.float32)
+
+
+TAPS16 = np.array([  # alsa/main.c:389-407 of the reference, cast to f32
+    -0.131625603115805, 0.103820148451119, 0.096541374482813, 0.102280926834003,
+    0.113689768997426, 0.125850624234278, 0.135740574367069, 0.141133806318268,
+    0.141133806318268, 0.135740574367069, 0.125850624234278, 0.113689768997426,
+    0.102280926834003, 0.096541374482813, 0.103820148451119, -0.131625603115805], dtype=np.float32)
+
+
+def make_fir(args, rank, nh):
+    taps = TAPS16 if nh == 16 else sinc_taps(nh)
+    x = uniform((args.channels, args.samples), 0xD5B0 + 3 + rank, "cuda")
+    y = torch.empty_like(x)
+    plan = dsp_amd.FirPlan(taps, "f32")
+    units = args.channels * args.samples
+    compute_bound = 2.0 * nh / 8.0 > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS
+    info = dict(kernel=plan.variant, units=units, unit_name="samples", nh=nh,
+                flop_per_unit=2.0 * nh, bytes_per_unit=8.0, bound="fp32" if compute_bound else "hbm",
+                samples_per_unit=1,
+                workload="batched FIR, %d taps, %d channels x %d samples per GPU" % (nh, args.channels, args.samples))
+    return (lambda: plan.exec(x, args.samples, y=y)), info, (plan, x, y)
+
+
+def roofline(info, ms_per_launch):
+    sec = ms_per_launch * 1e-3
+    if info["bound"] == "hbm":
+        achieved = info["bytes_per_unit"] * info["units"] / sec / 1e9
+        return {"bound": "hbm", "kernel": info["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launch_ms": round(ms_per_launch, 4),
+                "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
+    achieved = info["flop_per_unit"] * info["units"] / sec / 1e12
+    return {"bound": "fp32_vector", "kernel": info["kernel"], "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+            "launch_ms": round(ms_per_launch, 4),
+            "hbm_frac": round(info["bytes_per_unit"] * info["units"] / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_flop_per_launch": info["flop_per_unit"] * info["units"]}
+
+
+# ---------------------------------------------------------------------------
+# CPU baseline (the oracle's port; rank 0, N = 1 only)
+# ---------------------------------------------------------------------------
+
+def cpu_baseline_fft(n=1024, target_s=12.0):
+    """The reference's FFTs are FFTW3's, which is not installed, so the baseline is the
+    oracle's double radix-2 (fft/doc/notes:8-22), one thread, twiddles from a table,
+    built -O3 ("port").  Timed on a bounded number of frames."""
+    import ctypes as C
+    import oracle
+    L = oracle.lib("_fast")
+    rng = np.random.default_rng(0)
+    probe = 2048
+    z = rng.uniform(-1, 1, (probe, n, 2))
+    out = np.empty_like(z)
+    dp = C.POINTER(C.c_double)
+    t0 = time.perf_counter()
+    L.oracle_fft_batch(z.ctypes.data_as(dp), out.ctypes.data_as(dp), n, probe, -1, 1)
+    per = (time.perf_counter() - t0) / probe
+    frames = int(max(probe, min(1 << 20, target_s / per)))
+    reps = max(1, frames // probe)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.oracle_fft_batch(z.ctypes.data_as(dp), out.ctypes.data_as(dp), n, probe, -1, 1)
+    dt = time.perf_counter() - t0
+    done = reps * probe
+    gflops = 5.0 * n * math.log2(n) * done / dt / 1e9
+    return {"value": round(gflops, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "frames_per_s": round(done / dt, 1),
+            "sample": "%d frames of N=%d (double radix-2 with twiddle table, gcc -O3, 1 thread; "
+                      "FFTW3, which the reference links, is not installed)" % (done, n)}
+
+
+def cpu_baseline_fir(nh, target_s=8.0):
+    """`convolve` of the reference restated (double, ascending taps), one thread, -O3."""
+    import ctypes as C
+    import oracle
+    L = oracle.lib("_fast")
+    rng = np.random.default_rng(0)
+    nx = 1 << 16
+    x = rng.uniform(-1, 1, nx)
+    h = np.asarray(TAPS16 if nh == 16 else sinc_taps(nh), dtype=np.float64)
+    y = np.empty(nx)
+    dp = C.POINTER(C.c_double)
+    t0 = time.perf_counter()
+    L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
+    per = time.perf_counter() - t0
+    reps = int(max(1, min(4096, target_s / per)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * nx / dt / 1e9, 5), "unit": "Gsamples/s", "cores": 1, "kind": "port",
+            "sample": "%d blocks of %d samples, %d taps (double, gcc -O3, 1 thread)" % (reps, nx, nh)}
+
+
+# ---------------------------------------------------------------------------
+
+def main():
+    args = parse()
+    world, rank, local = setup_dist(args)
+
+    if args.workload == "fft1024":
+        fn, info, keep = make_fft(args, rank)
+    else:
+        fn, info, keep = make_fir(args, rank, 127 if args.workload == "fir127" else 16)
+
+    dt, ms_launch = timed(fn, args.steps, args.warmup, world)
+    units_total = info["units"] * world * args.steps
+    gflops = info["flop_per_unit"] * units_total / dt / 1e9
+    gsamples = info["samples_per_unit"] * units_total / dt / 1e9
+
+    secondary = []
+    if rank == 0 and world == 1 and not args.no_secondary:
+        del keep, fn
+        torch.cuda.empty_cache()
+        for nh in (127, 16):
+            if args.workload == ("fir%d" % nh):
+                continue
+            f2, i2, k2 = make_fir(args, rank, nh)
+            d2, ms2 = timed(f2, 5, 2, 1)
+            secondary.append({"workload": i2["workload"],
+                              "gsamples_per_s": round(i2["units"] * 5 / d2 / 1e9, 2),
+                              "gflops": round(i2["flop_per_unit"] * i2["units"] * 5 / d2 / 1e9, 1),
+                              "roofline": roofline(i2, ms2)})
+            del f2, k2
+            torch.cuda.empty_cache()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_fft() if args.workload == "fft1024" else cpu_baseline_fir(info["nh"])
+
+    if rank == 0:
+        is_fft = args.workload == "fft1024"
+        line = {
+            "metric": "FFT GFLOP/s (N=1024, c2c f32, 5*N*log2(N) flop per frame)" if is_fft
+                      else "Gsamples/s batched FIR (%d taps, f32)" % info["nh"],
+            "value": round(gflops if is_fft else gsamples, 2),
+            "unit": "GFLOP/s" if is_fft else "Gsamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": info["workload"], "kernel": info["kernel"], "per_gpu_units": info["units"],
+                       "unit_name": info["unit_name"], "sharding": "frames/channels split across ranks, no collective"},
+            "gsamples_per_s": round(gsamples, 2), "gflops": round(gflops, 1),
+            "roofline": roofline(info, ms_launch),
+            "cpu_baseline": cpu,
+            "secondary": secondary,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
