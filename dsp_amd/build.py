@@ -17,10 +17,12 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
 
 # source -> extra flags.  fir_direct keeps products and sums as written (its
-# fused multiply-adds are explicit), which the bit-exact double path relies on.
+# fused multiply-adds are explicit), which the bit-exact double path relies on;
+# MFMA accumulators stay in ordinary VGPRs (gfx950 has one unified file), which
+# keeps hipcc from shuffling them through AGPR copies inside the tap loop.
 SOURCES = {
     "runtime.cpp": ["-x", "hip"],
-    "fir_direct.hip": ["-ffp-contract=off"],
+    "fir_direct.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"],
     "fft_stockham.hip": [],
     "wrappers.cpp": ["-x", "hip"],
 }

@@ -1,11 +1,22 @@
 // Direct (time-domain) batched FIR / convolution for gfx950.
 //
-// One workgroup of 256 lanes produces a tile of 256*R*G consecutive outputs of
-// one channel.  The tile's input window (tile + tap halo) is staged once in
-// LDS; each lane then keeps R consecutive outputs per group in registers and
-// slides over the taps in blocks of NHB: per block it reads R+NHB-1 inputs
-// from LDS with 16-byte reads and issues R*NHB FMAs whose tap operand is a
-// scalar register (taps are wave-uniform, fetched through the scalar cache).
+// Two kernels share one staging scheme: a workgroup of 256 lanes produces a
+// tile of consecutive outputs of one channel, and the tile's input window (tile
+// + tap halo, zero / history filled at the edges) is staged once in LDS.
+//
+//  * fir_mfma_kernel (f32, the measured path): the convolution of a 16-output
+//    block is a 16 x K Toeplitz matrix of taps times a K x 16 matrix whose
+//    column n is the input window of block n, so 16 blocks (256 outputs) are
+//    one chain of v_mfma_f32_16x16x4_f32 instructions over K = nh + 15 window
+//    positions.  That instruction is an exact f32 FMA chain at the full f32
+//    vector rate; nh of every nh + 15 products are useful.  Each wave keeps four
+//    such tiles (four independent accumulators) in flight, operands come from
+//    LDS as one 4-byte read per MFMA, and a tile's 256 results leave as one
+//    fully coalesced 16-byte-per-lane store.
+//  * fir_direct_kernel (f64 host wrappers): register-blocked vector MACs, each
+//    lane keeping R consecutive outputs per group and sliding over the taps in
+//    blocks of NHB with scalar-register tap operands.  Products and sums are
+//    rounded separately in the reference's order, so results are bit-exact.
 //
 //   y[c][i] = sum_{j<nh, 0<=i-j<nx} h[j] * x[c][i-j]
 //
@@ -29,6 +40,7 @@ struct FirParams {
     unsigned nxx, nx, nh, nhp;
     unsigned tiles_per_chan;
     unsigned flags;
+    unsigned ntiles_total, tiles_per_block;  // MFMA kernel: tiles over all channels / per workgroup
 };
 
 template <typename T> struct Vec4;
@@ -168,6 +180,209 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// f32 Toeplitz-MFMA kernel
+// ---------------------------------------------------------------------------
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaTile = 4096;  // outputs per workgroup: 4 waves x 4 tiles x 256
+constexpr int kMfmaSeg = 2048;   // taps per LDS staging round
+
+// 16 consecutive floats, then one pad: lanes that read 16 floats apart (the 16
+// columns of an MFMA B operand) land on 16 different banks.
+__device__ __forceinline__ unsigned xpad(unsigned l) { return l + (l >> 4); }
+constexpr unsigned mfma_lds_floats(unsigned seglen)
+{
+    // padded input window + reversed tap table with 15 leading and >= 33 trailing zeros
+    return (kMfmaTile + seglen + 16) / 16 * 17 + 17 + seglen + 48;
+}
+
+// Each workgroup walks `tiles_per_block` consecutive tiles.  A "unit" is one
+// (tile, tap segment) pair; while the MFMA loop of unit u runs out of LDS, the
+// input window of unit u+1 is already on its way from HBM into registers, and
+// is written to LDS once the loop is done (one LDS buffer, two barriers).
+// NIT = staging registers per lane = ceil((tile + segment - 1) / 256).
+template <int NIT>
+__global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *lds = reinterpret_cast<float *>(smem_raw);
+
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63, wave = t >> 6;
+    const bool drop_first = (p.flags & DSPMI_FIR_DROP_FIRST) != 0;
+    const long nx = p.nx, nh = p.nh;
+
+    const unsigned seg_cap = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
+    float *xs = lds;                                              // padded window
+    float *hr = lds + (kMfmaTile + seg_cap + 16) / 16 * 17 + 17;  // reversed taps
+
+    const int nseg = (p.nhp + kMfmaSeg - 1) / kMfmaSeg;
+    const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
+    const long tile_hi = min(tile_lo + (long)p.tiles_per_block, (long)p.ntiles_total);
+    const long nunits = (tile_hi - tile_lo) * nseg;
+
+    // A operand: lane holds row i = lane&15, window position kk = lane>>4 of each 4-step
+    const unsigned a_base = (lane >> 4) + 15 - (lane & 15);
+    // B operand: lane holds column n = lane&15 (outputs 16n..16n+15 of the tile), position kk
+    const unsigned b_base = wave * (1024 / 16 * 17) + 17 * (lane & 15) + (lane >> 4);
+
+    float stage[NIT];
+
+    struct Unit {
+        const float *xrow, *hrow;
+        long sbase;
+        int seg0, seglen, nstage;
+        bool plain;
+    };
+    auto describe = [&](long unit) {
+        Unit d;
+        const long gt = tile_lo + unit / nseg;
+        const int seg = (int)(unit % nseg);
+        const unsigned chan = (unsigned)(gt / p.tiles_per_chan);
+        const long tile_start = (gt - (long)chan * p.tiles_per_chan) * kMfmaTile;
+        d.seg0 = seg * kMfmaSeg;
+        d.seglen = min((int)p.nhp - d.seg0, kMfmaSeg);
+        d.sbase = tile_start - d.seg0 - d.seglen + 1;
+        d.nstage = kMfmaTile + d.seglen - 1;
+        d.xrow = p.x + (size_t)chan * p.x_stride;
+        d.hrow = p.hist ? p.hist + (size_t)chan * p.hist_stride : nullptr;
+        // A buffer load returns 0 for any offset outside [0, nx*4): exactly the zero extension
+        // on both sides of the row.  History, the conv1 quirk and rows too long for a 32-bit
+        // byte offset are staged by the checked loop in commit() instead.
+        d.plain = nx <= (1l << 29) && !(d.hrow && d.sbase < 0) && !(drop_first && d.sbase <= 0);
+        return d;
+    };
+
+    // global -> registers for one unit (asynchronous until the registers are read)
+    auto fetch = [&](const Unit &d) {
+        if (d.plain) {
+            // the descriptor must be provably wave-uniform or every load is wrapped in a
+            // serialising loop: rebuild the row pointer from scalar halves
+            const uintptr_t row = reinterpret_cast<uintptr_t>(d.xrow);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)row);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(row >> 32));
+            float *base = reinterpret_cast<float *>(((uintptr_t)hi << 32) | lo);
+            const int bytes = __builtin_amdgcn_readfirstlane((int)(nx * 4));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+            // the whole byte offset goes in the per-lane operand: only that operand (plus the
+            // instruction's immediate) takes part in the range check
+            const int sb = __builtin_amdgcn_readfirstlane((int)d.sbase);
+            if (sb >= 0) {
+                const int voff = (sb + (int)t) * 4;
+#pragma unroll
+                for (int it = 0; it < NIT; it++)
+                    stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + it * 1024, 0, 0));
+            } else {
+                // left edge: the offset is unsigned to the hardware, so samples before the
+                // row are sent to an offset that is out of range for every row length
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int s = sb + (int)t + 256 * it;
+                    stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, s < 0 ? 0x7ffffff0 : s * 4, 0, 0));
+                }
+            }
+        }
+    };
+
+    // registers -> LDS, plus the segment's reversed tap table when it changes
+    auto commit = [&](const Unit &d, bool first) {
+        const unsigned l0 = xpad(t);  // xpad(t + 256*it) = xpad(t) + 272*it
+        if (d.plain) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++)
+                if (it < NIT - 1 || (int)(t + 256 * it) < d.nstage) xs[l0 + 272 * it] = stage[it];
+        } else {
+            for (int l = t; l < d.nstage; l += 256) {
+                const long s = d.sbase + l;
+                float v = 0.f;
+                if (s >= 0) {
+                    if (s < nx && !(drop_first && s == 0)) v = d.xrow[s];
+                } else if (d.hrow && s >= 1 - nh) {
+                    v = d.hrow[nh - 1 + s];
+                }
+                xs[xpad(l)] = v;
+            }
+        }
+        if (t < 17) xs[xpad(d.nstage) + t] = 0.f;  // positions only zero taps multiply
+        if (first || nseg > 1) {
+            // hr[m + 15] = h[seg0 + seglen - 1 - m]; zeros on both sides
+            for (int m = t; m < d.seglen + 48; m += 256) {
+                const int k = m - 15;
+                hr[m] = (k >= 0 && k < d.seglen) ? p.taps[d.seg0 + d.seglen - 1 - k] : 0.f;
+            }
+        }
+    };
+
+    if (nunits <= 0) return;
+    Unit next = describe(0);
+    fetch(next);
+    commit(next, true);
+    __syncthreads();
+
+    f32x4 acc[4];
+    for (long unit = 0; unit < nunits; unit++) {
+        const bool more = unit + 1 < nunits;
+        if (more) {
+            next = describe(unit + 1);
+            fetch(next);
+        }
+
+        const int seg = (int)(unit % nseg);
+        const int seglen = min((int)p.nhp - seg * kMfmaSeg, kMfmaSeg);  // multiple of 16
+        if (seg == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+
+        const float *ap = hr + a_base;
+        const float *bp = xs + b_base;
+        const int nu = (seglen + 16) / 16;  // 16 window positions (4 MFMA steps) per iteration
+        for (int u = 0; u < nu; u++) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float a = ap[4 * v];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float b = bp[q * (256 / 16 * 17) + 4 * v];
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+                }
+            }
+            ap += 16;
+            bp += 17;
+        }
+
+        if (seg == nseg - 1) {
+            // D layout: column n = lane&15, rows 4*(lane>>4) .. +3 -> 4 consecutive outputs per
+            // lane; the wave's 64 lanes cover 1 KiB contiguously.
+            const long gt = tile_lo + unit / nseg;
+            const unsigned chan = (unsigned)(gt / p.tiles_per_chan);
+            const long tile_start = (gt - (long)chan * p.tiles_per_chan) * kMfmaTile;
+            float *__restrict__ yrow = p.y + (size_t)chan * p.y_stride;
+            const bool y_vec = (reinterpret_cast<uintptr_t>(yrow) % 16) == 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const long o0 = tile_start + wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+                if (y_vec && o0 + 4 <= (long)p.nxx) {
+                    *reinterpret_cast<f32x4 *>(&yrow[o0]) = acc[q];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (o0 + r < (long)p.nxx) yrow[o0 + r] = acc[q][r];
+                }
+            }
+        }
+
+        if (more) {
+            __syncthreads();  // every wave is done reading this unit's window
+            commit(next, false);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -186,12 +401,35 @@ struct dspmi_fir_plan {
 namespace {
 
 enum {
-    V_F32_SHORT = 0,  // R=4 G=4 NHB=16: HBM-bound regime, lane-contiguous 16-byte traffic
-    V_F32_LONG,       // R=8 G=2 NHB=16: FMA-bound regime
+    V_F32_MFMA = 0,   // Toeplitz MFMA 16x16x4, every tap count
+    V_F32_SHORT,      // vector FMA, R=4 G=4 NHB=16 (kept for A/B runs: DSPMI_FIR_VARIANT=valu)
+    V_F32_LONG,       // vector FMA, R=8 G=2 NHB=16
     V_F64_EXACT,      // R=4 G=2 NHB=8, separate mul/add, ascending taps
 };
 
-const char *const kVariantName[] = {"fir_f32_r4g4_b16", "fir_f32_r8g2_b16", "fir_f64_exact_r4g2_b8"};
+const char *const kVariantName[] = {"fir_f32_mfma16x16x4", "fir_f32_valu_r4g4_b16", "fir_f32_valu_r8g2_b16",
+                                    "fir_f64_exact_r4g2_b8"};
+
+int launch_mfma(FirParams<float> p, unsigned nchan, hipStream_t stream)
+{
+    const unsigned seg = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
+    const size_t lds = mfma_lds_floats(seg) * sizeof(float);
+    const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
+    if (tiles == 0) return DSPMI_OK;
+    if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
+    p.ntiles_total = (unsigned)tiles;
+    // a few thousand workgroups keep all 256 CUs (8 resident workgroups each) busy for
+    // several rounds; beyond that, longer walks amortise the pipeline fill of each workgroup
+    unsigned tpb = (unsigned)(tiles / 16384);
+    p.tiles_per_block = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
+    const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
+    if (seg <= 256)
+        hipLaunchKernelGGL(fir_mfma_kernel<(kMfmaTile + 256 + 255) / 256>, dim3(blocks), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL(fir_mfma_kernel<(kMfmaTile + kMfmaSeg + 255) / 256>, dim3(blocks), dim3(256), lds, stream, p);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
 constexpr int kSeg = 2048;    // taps per LDS staging round
@@ -237,8 +475,13 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         delete pl;
         return dspmi::fail(DSPMI_EIO, "fir_create: %s", hipGetErrorString(e));
     }
-    if (precision == DSPMI_F64) pl->variant = V_F64_EXACT;
-    else pl->variant = nh <= 32 ? V_F32_SHORT : V_F32_LONG;
+    if (precision == DSPMI_F64) {
+        pl->variant = V_F64_EXACT;
+    } else {
+        const char *force = getenv("DSPMI_FIR_VARIANT");
+        if (force && !strcmp(force, "valu")) pl->variant = nh <= 32 ? V_F32_SHORT : V_F32_LONG;
+        else pl->variant = V_F32_MFMA;
+    }
     *out = pl;
     return DSPMI_OK;
 }
@@ -259,6 +502,10 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if constexpr (sizeof(T) == 4) {
+        if (pl->variant == V_F32_MFMA) {
+            p.tiles_per_chan = (nxx + kMfmaTile - 1) / kMfmaTile;
+            return launch_mfma(p, nchan, s);
+        }
         if (pl->variant == V_F32_SHORT) {
             p.tiles_per_chan = (nxx + 4095) / 4096;
             return launch<float, 4, 4, 16, false, false>(p, nchan, s);
