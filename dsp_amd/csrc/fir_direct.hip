@@ -190,13 +190,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMfmaTile = 4096;  // outputs per workgroup: 4 waves x 4 tiles x 256
 constexpr int kMfmaSeg = 2048;   // taps per LDS staging round
 
-// 16 consecutive floats, then one pad: lanes that read 16 floats apart (the 16
-// columns of an MFMA B operand) land on 16 different banks.
-__device__ __forceinline__ unsigned xpad(unsigned l) { return l + (l >> 4); }
+// 16 consecutive floats, then two pads.  One 4-byte LDS read serves 32 lanes: the 16
+// columns of an MFMA B operand (16 floats apart) at two adjacent window positions.
+// With rows 18 floats apart the columns fall on the 16 even banks and the second
+// position on the 16 odd ones, so the read is conflict-free.
+constexpr unsigned kRow = 18;
+__device__ __forceinline__ unsigned xpad(unsigned l) { return l + 2 * (l >> 4); }
+constexpr unsigned mfma_window_floats(unsigned seglen) { return (kMfmaTile + seglen + 16) / 16 * kRow + kRow; }
 constexpr unsigned mfma_lds_floats(unsigned seglen)
 {
     // padded input window + reversed tap table with 15 leading and >= 33 trailing zeros
-    return (kMfmaTile + seglen + 16) / 16 * 17 + 17 + seglen + 48;
+    return mfma_window_floats(seglen) + seglen + 48;
 }
 
 // Each workgroup walks `tiles_per_block` consecutive tiles.  A "unit" is one
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 
     const unsigned seg_cap = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
     float *xs = lds;                                              // padded window
-    float *hr = lds + (kMfmaTile + seg_cap + 16) / 16 * 17 + 17;  // reversed taps
+    float *hr = lds + mfma_window_floats(seg_cap);                // reversed taps
 
     const int nseg = (p.nhp + kMfmaSeg - 1) / kMfmaSeg;
     const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
     // A operand: lane holds row i = lane&15, window position kk = lane>>4 of each 4-step
     const unsigned a_base = (lane >> 4) + 15 - (lane & 15);
     // B operand: lane holds column n = lane&15 (outputs 16n..16n+15 of the tile), position kk
-    const unsigned b_base = wave * (1024 / 16 * 17) + 17 * (lane & 15) + (lane >> 4);
+    const unsigned b_base = wave * (1024 / 16 * kRow) + kRow * (lane & 15) + (lane >> 4);
 
     float stage[NIT];
 
@@ -289,11 +293,11 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 
     // registers -> LDS, plus the segment's reversed tap table when it changes
     auto commit = [&](const Unit &d, bool first) {
-        const unsigned l0 = xpad(t);  // xpad(t + 256*it) = xpad(t) + 272*it
+        const unsigned l0 = xpad(t);  // xpad(t + 256*it) = xpad(t) + 16*kRow*it
         if (d.plain) {
 #pragma unroll
             for (int it = 0; it < NIT; it++)
-                if (it < NIT - 1 || (int)(t + 256 * it) < d.nstage) xs[l0 + 272 * it] = stage[it];
+                if (it < NIT - 1 || (int)(t + 256 * it) < d.nstage) xs[l0 + 16 * kRow * it] = stage[it];
         } else {
             for (int l = t; l < d.nstage; l += 256) {
                 const long s = d.sbase + l;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
                 xs[xpad(l)] = v;
             }
         }
-        if (t < 17) xs[xpad(d.nstage) + t] = 0.f;  // positions only zero taps multiply
+        if (t < kRow) xs[xpad(d.nstage) + t] = 0.f;  // positions only zero taps multiply
         if (first || nseg > 1) {
             // hr[m + 15] = h[seg0 + seglen - 1 - m]; zeros on both sides
             for (int m = t; m < d.seglen + 48; m += 256) {
@@ -346,12 +350,12 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
                 const float a = ap[4 * v];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const float b = bp[q * (256 / 16 * 17) + 4 * v];
+                    const float b = bp[q * (256 / 16 * kRow) + 4 * v];
                     acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
                 }
             }
             ap += 16;
-            bp += 17;
+            bp += kRow;
         }
 
         if (seg == nseg - 1) {
@@ -413,20 +417,35 @@ const char *const kVariantName[] = {"fir_f32_mfma16x16x4", "fir_f32_valu_r4g4_b1
 int launch_mfma(FirParams<float> p, unsigned nchan, hipStream_t stream)
 {
     const unsigned seg = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
-    const size_t lds = mfma_lds_floats(seg) * sizeof(float);
+    size_t lds = mfma_lds_floats(seg) * sizeof(float);
+    {
+        // Resident workgroups per CU are capped by inflating the LDS request.  A short
+        // filter is an HBM-bound stream, and the stream is measurably faster with 2-3
+        // workgroups (8-12 waves) per CU than with 8; a long filter is MFMA-bound and
+        // wants every wave it can get to cover staging and stores.
+        const char *env = getenv("DSPMI_FIR_BPC");
+        const int bpc = env && atoi(env) > 0 ? atoi(env) : (p.nhp <= 64 ? 2 : 8);
+        const size_t want = (160 * 1024) / bpc - 512;
+        if (want > lds) lds = want;
+    }
     const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
     if (tiles == 0) return DSPMI_OK;
     if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
     p.ntiles_total = (unsigned)tiles;
-    // a few thousand workgroups keep all 256 CUs (8 resident workgroups each) busy for
-    // several rounds; beyond that, longer walks amortise the pipeline fill of each workgroup
+    // a few thousand workgroups keep all 256 CUs busy for several rounds; beyond that,
+    // longer walks amortise the pipeline fill of each workgroup
     unsigned tpb = (unsigned)(tiles / 16384);
     p.tiles_per_block = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
-    if (seg <= 256)
-        hipLaunchKernelGGL(fir_mfma_kernel<(kMfmaTile + 256 + 255) / 256>, dim3(blocks), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL(fir_mfma_kernel<(kMfmaTile + kMfmaSeg + 255) / 256>, dim3(blocks), dim3(256), lds, stream, p);
+    auto k17 = fir_mfma_kernel<(kMfmaTile + 256 + 255) / 256>;
+    auto k24 = fir_mfma_kernel<(kMfmaTile + kMfmaSeg + 255) / 256>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k17), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k24), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(seg <= 256 ? k17 : k24, dim3(blocks), dim3(256), lds, stream, p);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
