@@ -42,6 +42,22 @@ template <typename T> __device__ __forceinline__ C<T> cmul(C<T> a, C<T> b)
 // multiply by -i (forward quarter turn)
 template <typename T> __device__ __forceinline__ C<T> mul_mi(C<T> a) { return {a.im, -a.re}; }
 
+// nontemporal (streaming) global access of one complex point
+template <typename T>
+__device__ __forceinline__ C<T> nt_load(const C<T> *p)
+{
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 v = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(p));
+    return {v.x, v.y};
+}
+template <typename T>
+__device__ __forceinline__ void nt_store(C<T> q, C<T> *p)
+{
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2 v = {q.re, q.im};
+    __builtin_nontemporal_store(v, reinterpret_cast<V2 *>(p));
+}
+
 // cos/sin of 2*pi*k/16, k = 0..15
 __device__ constexpr double kCos16[16] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
                                           0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
@@ -151,7 +167,9 @@ __device__ __forceinline__ void load_twiddles(C<T> *twr, const C<T> *__restrict_
 // One pass over the P register-resident points of this lane.
 //   FIRST: sources are v as loaded from global by the caller; otherwise read from LDS
 //   LAST : results stay in v (caller stores to global); otherwise written to LDS
-template <typename T, int N, int NT, int R, int NS, bool FIRST, bool LAST, bool TWREG>
+// Twiddle source (TW): 0 = the global table (through L1), 1 = registers filled once per
+// lane (twr), 2 = a per-workgroup LDS table laid out [r-1][j mod NS] (twr points at it).
+template <typename T, int N, int NT, int R, int NS, bool FIRST, bool LAST, int TW>
 __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
 {
     constexpr int P = N / NT, NB = P / R;
@@ -170,7 +188,8 @@ __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, co
 #pragma unroll
             for (int r = 1; r < R; r++) {
                 C<T> w;
-                if constexpr (TWREG) w = twr[b * (R - 1) + r - 1];
+                if constexpr (TW == 1) w = twr[b * (R - 1) + r - 1];
+                else if constexpr (TW == 2) w = twr[(r - 1) * NS + k];
                 else w = tw[k * r * (N / (NS * R))];
                 v[b * R + r] = cmul(v[b * R + r], w);
             }
@@ -191,7 +210,7 @@ __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, co
 
 template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
 
-template <typename T, int N, int NT, int R0, int R1, int R2, int R3, bool TWREG>
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T> *in, C<T> *out,
                                                                       const C<T> *__restrict__ tw, size_t batch,
                                                                       int backward)
@@ -210,40 +229,59 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
     const unsigned tl = threadIdx.x % NT;
     C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
 
-    C<T> tw1[cmax(1, TWREG ? tw_count(P, R1, NS1) : 0)];
-    C<T> tw2[cmax(1, TWREG ? tw_count(P, R2, NS2) : 0)];
-    C<T> tw3[cmax(1, TWREG ? tw_count(P, R3, NS3) : 0)];
+    constexpr bool TWREG = TW == 1;
+    C<T> tw1r[cmax(1, TWREG ? tw_count(P, R1, NS1) : 0)];
+    C<T> tw2r[cmax(1, TWREG ? tw_count(P, R2, NS2) : 0)];
+    C<T> tw3r[cmax(1, TWREG ? tw_count(P, R3, NS3) : 0)];
+    const C<T> *tw1 = tw1r, *tw2 = tw2r, *tw3 = tw3r;
     if constexpr (TWREG) {
-        load_twiddles<T, N, NT, R1, NS1>(tw1, tw, tl);
-        load_twiddles<T, N, NT, R2, NS2>(tw2, tw, tl);
-        load_twiddles<T, N, NT, R3, NS3>(tw3, tw, tl);
+        load_twiddles<T, N, NT, R1, NS1>(tw1r, tw, tl);
+        load_twiddles<T, N, NT, R2, NS2>(tw2r, tw, tl);
+        load_twiddles<T, N, NT, R3, NS3>(tw3r, tw, tl);
+    }
+    if constexpr (TW == 2) {
+        // per-workgroup twiddle tables behind the frame buffers: pass p holds
+        // W^{k*r}, r = 1..R-1, k < NS, as [r-1][k] so a wave reads contiguous entries
+        C<T> *t1 = reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N);
+        C<T> *t2 = t1 + (R1 > 1 ? (R1 - 1) * NS1 : 0);
+        C<T> *t3 = t2 + (R2 > 1 ? (R2 - 1) * NS2 : 0);
+        if constexpr (R1 > 1)
+            for (unsigned i = threadIdx.x; i < (R1 - 1) * NS1; i += BT) t1[i] = tw[(i % NS1) * (i / NS1 + 1) * (N / (NS1 * R1))];
+        if constexpr (R2 > 1)
+            for (unsigned i = threadIdx.x; i < (R2 - 1) * NS2; i += BT) t2[i] = tw[(i % NS2) * (i / NS2 + 1) * (N / (NS2 * R2))];
+        if constexpr (R3 > 1)
+            for (unsigned i = threadIdx.x; i < (R3 - 1) * NS3; i += BT) t3[i] = tw[(i % NS3) * (i / NS3 + 1) * (N / (NS3 * R3))];
+        __syncthreads();
+        tw1 = t1; tw2 = t2; tw3 = t3;
     }
     const T sgn = backward ? T(-1) : T(1);
 
     const size_t nfb = (batch + FPB - 1) / FPB;
-    for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
-        const size_t frame = fb * FPB + slot;
-        const bool active = frame < batch;
-        const C<T> *src = in + frame * N;
-        C<T> *dst = out + frame * N;
 
-        C<T> v[P];
-        // first pass reads global memory: lane-contiguous, R0 loads N/R0 apart
+    // first pass reads global memory: lane-contiguous, R0 loads N/R0 apart
+    auto load_frame = [&](C<T> (&v)[P], size_t fb) {
+        const size_t frame = fb * FPB + slot;
+        const C<T> *src = in + frame * N;
+        const bool active = frame < batch;
 #pragma unroll
         for (int b = 0; b < P / R0; b++)
 #pragma unroll
             for (int r = 0; r < R0; r++) {
                 C<T> q = {T(0), T(0)};
-                if (active) q = src[tl + NT * b + r * (N / R0)];
-                q.im *= sgn;
+                if (active) q = (NTMEM & 1) ? nt_load(&src[tl + NT * b + r * (N / R0)]) : src[tl + NT * b + r * (N / R0)];
                 v[b * R0 + r] = q;
             }
-
-        fft_pass<T, N, NT, R0, 1, true, NPASS == 1, TWREG>(v, lds, nullptr, tw, tl);
-        if constexpr (R1 > 1) fft_pass<T, N, NT, R1, NS1, false, NPASS == 2, TWREG>(v, lds, tw1, tw, tl);
-        if constexpr (R2 > 1) fft_pass<T, N, NT, R2, NS2, false, NPASS == 3, TWREG>(v, lds, tw2, tw, tl);
-        if constexpr (R3 > 1) fft_pass<T, N, NT, R3, NS3, false, NPASS == 4, TWREG>(v, lds, tw3, tw, tl);
-
+    };
+    auto process = [&](C<T> (&v)[P], size_t fb) {
+        const size_t frame = fb * FPB + slot;
+        const bool active = frame < batch;
+        C<T> *dst = out + frame * N;
+#pragma unroll
+        for (int i = 0; i < P; i++) v[i].im *= sgn;
+        fft_pass<T, N, NT, R0, 1, true, NPASS == 1, TW>(v, lds, nullptr, tw, tl);
+        if constexpr (R1 > 1) fft_pass<T, N, NT, R1, NS1, false, NPASS == 2, TW>(v, lds, tw1, tw, tl);
+        if constexpr (R2 > 1) fft_pass<T, N, NT, R2, NS2, false, NPASS == 3, TW>(v, lds, tw2, tw, tl);
+        if constexpr (R3 > 1) fft_pass<T, N, NT, R3, NS3, false, NPASS == 4, TW>(v, lds, tw3, tw, tl);
         // last pass writes global memory: butterfly j, output r goes to j + r*N/RLAST
         if (active) {
 #pragma unroll
@@ -252,8 +290,36 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
                 for (int r = 0; r < RLAST; r++) {
                     C<T> q = v[b * RLAST + r];
                     q.im *= sgn;
-                    dst[tl + NT * b + r * NSLAST] = q;
+                    if constexpr ((NTMEM & 2) != 0) nt_store(q, &dst[tl + NT * b + r * NSLAST]);
+                    else dst[tl + NT * b + r * NSLAST] = q;
                 }
+        }
+    };
+
+    if constexpr (PREFETCH) {
+        // two register sets: the next frame's loads are in flight while this one is computed
+        const size_t step = gridDim.x;
+        size_t fb = blockIdx.x;
+        if (fb >= nfb) return;
+        C<T> va[P], vb[P];
+        load_frame(va, fb);
+        while (true) {
+            const bool more1 = fb + step < nfb;
+            if (more1) load_frame(vb, fb + step);
+            process(va, fb);
+            if (!more1) break;
+            fb += step;
+            const bool more2 = fb + step < nfb;
+            if (more2) load_frame(va, fb + step);
+            process(vb, fb);
+            if (!more2) break;
+            fb += step;
+        }
+    } else {
+        for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+            C<T> v[P];
+            load_frame(v, fb);
+            process(v, fb);
         }
     }
 }
@@ -366,21 +432,24 @@ struct dspmi_fft_plan {
     void *tw_half;    // exp(-2 pi i k / (n/2)) for the half-length transform of r2c / c2r (n even)
     void *work;       // scratch for r2c / c2r: batch_cap * (n/2) complex
     size_t work_cap;  // in frames
-    fft_launch_fn launch;
-    fft_launch_fn launch_half;
+    fft_launch_fn launch, launch_stream;
+    fft_launch_fn launch_half, launch_half_stream;
     char name[64];
 };
 
 namespace {
 
-template <typename T, int N, int NT, int R0, int R1, int R2, int R3, bool TWREG>
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
 {
     constexpr int BT = block_threads<NT>();
     constexpr int FPB = BT / NT;
     constexpr bool single_pass = R1 == 1 && R2 == 1 && R3 == 1;  // global -> registers -> global
-    constexpr size_t lds = single_pass ? 0 : (size_t)FPB * padded_len(N) * sizeof(C<T>);
-    auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TWREG>;
+    constexpr size_t tw_entries = TW == 2 ? (R1 > 1 ? (R1 - 1) * R0 : 0) + (R2 > 1 ? (R2 - 1) * R0 * R1 : 0) +
+                                                (R3 > 1 ? (R3 - 1) * R0 * R1 * R2 : 0)
+                                          : 0;
+    constexpr size_t lds = single_pass ? 0 : ((size_t)FPB * padded_len(N) + tw_entries) * sizeof(C<T>);
+    auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TW, PREFETCH, NTMEM>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -389,13 +458,25 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     }
     if (batch == 0) return DSPMI_OK;
     const size_t nfb = (batch + FPB - 1) / FPB;
-    // enough workgroups to fill every CU several times over; each loops over frames
+    // one resident set of workgroups, each looping over frames
     size_t per_cu = lds ? (160 * 1024) / lds : 8;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
+    size_t lds_req = lds;
+    {
+        // experiment knob: resident workgroups per CU (LDS request inflated to enforce it)
+        const char *env = getenv("DSPMI_FFT_BPC");
+        if (env && atoi(env) > 0 && lds && (size_t)atoi(env) < per_cu) {
+            per_cu = atoi(env);
+            lds_req = (160 * 1024) / per_cu - 512;
+            if (lds_req < lds) lds_req = lds;
+            DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_req));
+        }
+    }
     size_t grid = (size_t)num_cu * per_cu;
     if (grid > nfb) grid = nfb;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in),
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds_req, s, static_cast<const C<T> *>(in),
                        static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), batch, backward);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
@@ -403,19 +484,29 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
 
 struct FftEntry {
     unsigned n;
-    fft_launch_fn fn;
+    fft_launch_fn fn;         // default cache policy
+    fft_launch_fn fn_stream;  // nontemporal loads and stores: batches far larger than the caches
     const char *name;
 };
 
-#define F32(N, NT, A, B, C_, D) {N, launch_c2c<float, N, NT, A, B, C_, D, true>, "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
-#define F64(N, NT, A, B, C_, D) {N, launch_c2c<double, N, NT, A, B, C_, D, false>, "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
+// f32: twiddles in a per-workgroup LDS table (registers stay free for the butterflies: 4 waves
+// per SIMD instead of 2); f64: twiddles read from the global table through L1.
+#define F32(N, NT, A, B, C_, D)                                                                             \
+    {N, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 3>, \
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
+#define F64(N, NT, A, B, C_, D)                                                                               \
+    {N, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, \
+     "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
 
 const FftEntry kF32[] = {
     F32(2, 1, 2, 1, 1, 1),          F32(4, 1, 4, 1, 1, 1),          F32(8, 1, 8, 1, 1, 1),
     F32(16, 1, 16, 1, 1, 1),        F32(32, 2, 16, 2, 1, 1),        F32(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
     F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),   F32(4096, 256, 16, 16, 16, 1),
-    F32(8192, 512, 16, 16, 16, 2),  F32(16384, 1024, 16, 16, 16, 4),
+    F32(8192, 512, 16, 16, 16, 2),
+    // 16384 points fill the LDS with the frame alone: twiddles come from the global table
+    {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 3>,
+     "fft_f32_n16384_r16x16x16x4"},
 };
 const FftEntry kF64[] = {
     F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),
@@ -425,8 +516,19 @@ const FftEntry kF64[] = {
     F64(8192, 512, 16, 16, 16, 2),
 };
 
+// alternative kernels for A/B runs: DSPMI_FFT_VARIANT=<index>
+const FftEntry kF32Alt1024[] = {
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, "fft_f32_n1024_r16x16x4_twreg"},
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true, 3>, "fft_f32_n1024_r16x16x4_twlds_pf"},
+    {1024, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false, 3>, "fft_f32_n1024_r16x8x8_twlds"},
+};
+
 const FftEntry *find_entry(unsigned n, int precision)
 {
+    if (n == 1024 && precision == DSPMI_F32) {
+        const char *env = getenv("DSPMI_FFT_VARIANT");
+        if (env && atoi(env) >= 1 && atoi(env) <= 3) return &kF32Alt1024[atoi(env) - 1];
+    }
     const FftEntry *tab = precision == DSPMI_F64 ? kF64 : kF32;
     const size_t cnt = precision == DSPMI_F64 ? sizeof(kF64) / sizeof(kF64[0]) : sizeof(kF32) / sizeof(kF32[0]);
     for (size_t i = 0; i < cnt; i++)
@@ -489,7 +591,9 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     pl->precision = precision;
     pl->n = n;
     pl->launch = e ? e->fn : nullptr;
+    pl->launch_stream = e ? e->fn_stream : nullptr;
     pl->launch_half = eh ? eh->fn : nullptr;
+    pl->launch_half_stream = eh ? eh->fn_stream : nullptr;
     snprintf(pl->name, sizeof pl->name, "%s", e ? e->name : (eh ? eh->name : "fft_n1"));
     hipDeviceProp_t prop;
     int rc = DSPMI_OK;
@@ -533,7 +637,12 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
         return DSPMI_OK;
     }
     if (!plan->launch) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_c2c: no complex kernel for n = %u", plan->n);
-    return plan->launch(in, out, plan->tw_n, batch, sign == DSPMI_BACKWARD, plan->num_cu, s);
+    // a batch that cannot stay in the 256 MiB last-level cache is a read-once / write-once
+    // stream: bypass the caches' allocation with nontemporal accesses
+    const size_t esz = plan->precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
+    const bool stream_policy = batch * (size_t)plan->n * esz >= ((size_t)256 << 20);
+    return (stream_policy ? plan->launch_stream : plan->launch)(in, out, plan->tw_n, batch, sign == DSPMI_BACKWARD,
+                                                                plan->num_cu, s);
 }
 
 int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
