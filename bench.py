@@ -144,17 +144,32 @@ def make_fir(args, rank, nh):
     return (lambda: plan.exec(x, args.samples, y=y)), info, (plan, x, y)
 
 
+def measured_traffic(info):
+    """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes
+    (profiles/r1_traffic.json), or None when the workload was not profiled at this size."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+    except Exception:
+        return None
+    key = None
+    if info.get("n") == 1024 and info["units"] == 1 << 20:
+        key = "fft_f32_n1024 x 1048576 frames"
+    elif "nh" in info and info["units"] == 512 << 20:
+        key = "fir_f32_mfma 512 ch x 1048576 samples"
+    return tab[key]["hbm_bytes"] if key in tab else None
+
+
 def roofline(info, ms_per_launch):
     sec = ms_per_launch * 1e-3
     if info["bound"] == "hbm":
         achieved = info["bytes_per_unit"] * info["units"] / sec / 1e9
         return {"bound": "hbm", "kernel": info["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(info),
                 "launch_ms": round(ms_per_launch, 4),
                 "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
     achieved = info["flop_per_unit"] * info["units"] / sec / 1e12
     return {"bound": "fp32_vector", "kernel": info["kernel"], "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": measured_traffic(info),
             "launch_ms": round(ms_per_launch, 4),
             "hbm_frac": round(info["bytes_per_unit"] * info["units"] / sec / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_flop_per_launch": info["flop_per_unit"] * info["units"]}
