@@ -168,7 +168,7 @@ def roofline(info, ms_per_launch):
                 "launch_ms": round(ms_per_launch, 4),
                 "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
     achieved = info["flop_per_unit"] * info["units"] / sec / 1e12
-    return {"bound": "fp32_vector", "kernel": info["kernel"], "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
+    return {"bound": "mfma", "dtype_peak": "f32 MFMA dense = FP32 vector peak", "kernel": info["kernel"], "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": measured_traffic(info),
             "launch_ms": round(ms_per_launch, 4),
             "hbm_frac": round(info["bytes_per_unit"] * info["units"] / sec / 1e9 / HBM_PEAK_GBS, 4),

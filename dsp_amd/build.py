@@ -24,6 +24,7 @@ SOURCES = {
     "runtime.cpp": ["-x", "hip"],
     "fir_direct.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"],
     "fft_stockham.hip": [],
+    "fft_plan.hip": [],
     "wrappers.cpp": ["-x", "hip"],
 }
 

@@ -1,0 +1,561 @@
+// FFT plans: the counterpart of fftw_plan_dft_1d / _r2c_1d / _c2r_1d as the
+// reference uses them (fftc/main.c:33-42, fft/src/main.c:156-166,
+// util/filter/filter.c:86-103), over the batched kernels of fft_stockham.hip.
+//
+//  * power-of-two lengths run the Stockham kernels directly;
+//  * any other length (the demos use 480 and 482: fftc/main.c:137, fir/src/main.c:154)
+//    runs Bluestein's chirp-z: x[n]*c[n] convolved with conj(c) through two
+//    power-of-two transforms of length M >= 2n-1, c[n] = exp(-i*pi*n^2/N);
+//  * real transforms of even length n use one complex transform of n/2 points plus an
+//    O(n) split / merge kernel; other real lengths go through the complex transform.
+//
+// All transforms are unnormalised in both directions (FFTW's convention).
+#include "common.h"
+#include "fft_internal.h"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace {
+
+template <typename T>
+struct alignas(2 * sizeof(T)) C {
+    T re, im;
+};
+
+template <typename T> __device__ __forceinline__ C<T> cmul(C<T> a, C<T> b)
+{
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+#define GRID_STRIDE(i, total) \
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (size_t)gridDim.x * blockDim.x)
+
+// ---- real <-> half-complex, n even ------------------------------------------------
+
+// Z = FFT_{n/2}(x[2m] + i x[2m+1]);  X[k] = E[k] + W_n^k O[k], k = 0..n/2, with
+// E[k] = (Z[k] + conj Z[h-k])/2, O[k] = -i (Z[k] - conj Z[h-k])/2, h = n/2, Z[h] = Z[0].
+template <typename T>
+__global__ __launch_bounds__(256) void r2c_split_kernel(const C<T> *__restrict__ z, C<T> *__restrict__ xout,
+                                                        const C<T> *__restrict__ twn, unsigned n, size_t batch)
+{
+    const unsigned h = n / 2;
+    GRID_STRIDE(i, batch * (size_t)(h + 1)) {
+        const size_t f = i / (h + 1);
+        const unsigned k = (unsigned)(i - f * (h + 1));
+        const C<T> *zf = z + f * h;
+        const C<T> a = zf[k == h ? 0 : k];
+        const C<T> b0 = zf[(h - k) % h];
+        const C<T> b = {b0.re, -b0.im};
+        const C<T> e = {(a.re + b.re) * T(0.5), (a.im + b.im) * T(0.5)};
+        const C<T> d = {(a.re - b.re) * T(0.5), (a.im - b.im) * T(0.5)};
+        const C<T> o = {d.im, -d.re};                            // -i * d
+        const C<T> w = (k == h) ? C<T>{T(-1), T(0)} : twn[k];    // exp(-2 pi i k / n)
+        const C<T> wo = cmul(w, o);
+        xout[f * (h + 1) + k] = {e.re + wo.re, e.im + wo.im};
+    }
+}
+
+// Unnormalised c2r: n * x equals the n/2-point backward transform of
+// Z[k] = (X[k] + conj X[h-k]) + i W_n^{-k} (X[k] - conj X[h-k]).
+template <typename T>
+__global__ __launch_bounds__(256) void c2r_merge_kernel(const C<T> *__restrict__ xin, C<T> *__restrict__ z,
+                                                        const C<T> *__restrict__ twn, unsigned n, size_t batch)
+{
+    const unsigned h = n / 2;
+    GRID_STRIDE(i, batch * (size_t)h) {
+        const size_t f = i / h;
+        const unsigned k = (unsigned)(i - f * h);
+        const C<T> *xf = xin + f * (h + 1);
+        C<T> a = xf[k];
+        C<T> b0 = xf[h - k];
+        // like FFTW's c2r, ignore the imaginary parts of the DC and Nyquist bins
+        if (k == 0) { a.im = T(0); b0.im = T(0); }
+        const C<T> b = {b0.re, -b0.im};
+        const C<T> s = {a.re + b.re, a.im + b.im};
+        const C<T> d = {a.re - b.re, a.im - b.im};
+        const C<T> w0 = twn[k];
+        const C<T> w = {w0.re, -w0.im};  // exp(+2 pi i k / n)
+        const C<T> wd = cmul(w, d);
+        z[f * h + k] = {s.re - wd.im, s.im + wd.re};  // s + i * wd
+    }
+}
+
+// ---- real transforms of any length through the complex transform -------------------
+
+template <typename T>
+__global__ __launch_bounds__(256) void real_to_complex_kernel(const T *__restrict__ x, C<T> *__restrict__ z, size_t total)
+{
+    GRID_STRIDE(i, total) z[i] = {x[i], T(0)};
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void take_bins_kernel(const C<T> *__restrict__ full, C<T> *__restrict__ bins, unsigned n,
+                                                        size_t batch)
+{
+    const unsigned nb = n / 2 + 1;
+    GRID_STRIDE(i, batch * (size_t)nb) {
+        const size_t f = i / nb;
+        bins[i] = full[f * n + (i - f * nb)];
+    }
+}
+
+// Hermitian extension of bins 0..n/2 to n points (imaginary parts of DC / Nyquist dropped).
+template <typename T>
+__global__ __launch_bounds__(256) void hermitian_extend_kernel(const C<T> *__restrict__ bins, C<T> *__restrict__ full,
+                                                               unsigned n, size_t batch)
+{
+    const unsigned nb = n / 2 + 1;
+    GRID_STRIDE(i, batch * (size_t)n) {
+        const size_t f = i / n;
+        const unsigned k = (unsigned)(i - f * n);
+        C<T> v;
+        if (k < nb) {
+            v = bins[f * nb + k];
+            if (k == 0 || (n % 2 == 0 && k == n / 2)) v.im = T(0);
+        } else {
+            v = bins[f * nb + (n - k)];
+            v.im = -v.im;
+        }
+        full[i] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void take_real_kernel(const C<T> *__restrict__ z, T *__restrict__ x, size_t total)
+{
+    GRID_STRIDE(i, total) x[i] = z[i].re;
+}
+
+// ---- Bluestein ------------------------------------------------------------------------
+
+// work[f][m] = x[f][m] * c[m] for m < n, 0 up to M; conj_in conjugates x (backward transform)
+template <typename T>
+__global__ __launch_bounds__(256) void bluestein_pre_kernel(const C<T> *__restrict__ x, const C<T> *__restrict__ chirp,
+                                                            C<T> *__restrict__ work, unsigned n, unsigned M, size_t batch,
+                                                            int conj_in)
+{
+    GRID_STRIDE(i, batch * (size_t)M) {
+        const size_t f = i / M;
+        const unsigned m = (unsigned)(i - f * M);
+        C<T> v = {T(0), T(0)};
+        if (m < n) {
+            v = x[f * n + m];
+            if (conj_in) v.im = -v.im;
+            v = cmul(v, chirp[m]);
+        }
+        work[i] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bluestein_mul_kernel(C<T> *__restrict__ work, const C<T> *__restrict__ filt,
+                                                            unsigned M, size_t batch)
+{
+    GRID_STRIDE(i, batch * (size_t)M) work[i] = cmul(work[i], filt[i % M]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bluestein_post_kernel(const C<T> *__restrict__ work, const C<T> *__restrict__ chirp,
+                                                             C<T> *__restrict__ out, unsigned n, unsigned M, size_t batch,
+                                                             int conj_out)
+{
+    GRID_STRIDE(i, batch * (size_t)n) {
+        const size_t f = i / n;
+        const unsigned k = (unsigned)(i - f * n);
+        C<T> v = cmul(work[f * M + k], chirp[k]);
+        if (conj_out) v.im = -v.im;
+        out[i] = v;
+    }
+}
+
+// ---- element-wise helpers for the host wrappers -------------------------------------
+
+// bins[f][k] *= g[k]  (real gain per bin; util/filter/filter.c:92-96)
+template <typename T>
+__global__ __launch_bounds__(256) void bin_gain_kernel(C<T> *__restrict__ bins, const T *__restrict__ g, unsigned nbin,
+                                                       size_t batch)
+{
+    GRID_STRIDE(i, batch * (size_t)nbin) {
+        const T gg = g[i % nbin];
+        C<T> v = bins[i];
+        v.re *= gg;
+        v.im *= gg;
+        bins[i] = v;
+    }
+}
+
+// out[f][i] = 2*|bins[f][i]| / scale, i < nout (fftc/main.c:80-105, fir/src/main.c:246-251)
+template <typename T>
+__global__ __launch_bounds__(256) void ps_abs_kernel(const C<T> *__restrict__ bins, T *__restrict__ out, unsigned nout,
+                                                     T scale, size_t batch, unsigned in_stride)
+{
+    GRID_STRIDE(i, batch * (size_t)nout) {
+        const size_t f = i / nout;
+        const C<T> v = bins[f * in_stride + (i - f * nout)];
+        out[i] = (T(2) * sqrt(v.re * v.re + v.im * v.im)) / scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T *__restrict__ x, T divisor, size_t total)
+{
+    GRID_STRIDE(i, total) x[i] = x[i] / divisor;
+}
+
+inline unsigned ew_grid(size_t total, int num_cu)
+{
+    size_t g = (total + 255) / 256;
+    const size_t cap = (size_t)num_cu * 8;
+    return (unsigned)(g < cap ? (g ? g : 1) : cap);
+}
+
+template <typename T>
+std::vector<C<T>> unit_circle(unsigned n, unsigned denom_mult)
+{
+    // exp(-2 pi i k / (n * denom_mult)) ... used with denom_mult = 1 for twiddles
+    std::vector<C<T>> tw(n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (unsigned k = 0; k < n; k++) {
+        const long double a = -two_pi * (long double)k / ((long double)n * denom_mult);
+        tw[k].re = (T)cosl(a);
+        tw[k].im = (T)sinl(a);
+    }
+    return tw;
+}
+
+template <typename T>
+int upload(void **dev, const std::vector<C<T>> &v)
+{
+    DSPMI_HIP(hipMalloc(dev, v.size() * sizeof(C<T>)));
+    DSPMI_HIP(hipMemcpy(*dev, v.data(), v.size() * sizeof(C<T>), hipMemcpyHostToDevice));
+    return DSPMI_OK;
+}
+
+int upload_twiddles(void **dev, unsigned n, int precision)
+{
+    return precision == DSPMI_F64 ? upload<double>(dev, unit_circle<double>(n, 1)) : upload<float>(dev, unit_circle<float>(n, 1));
+}
+
+// chirp c[m] = exp(-i pi m^2 / n), the angle reduced exactly: m^2 mod 2n
+template <typename T>
+std::vector<C<T>> chirp(unsigned n)
+{
+    std::vector<C<T>> c(n);
+    const long double pi = 3.141592653589793238462643383279502884L;
+    for (unsigned m = 0; m < n; m++) {
+        const unsigned long long r = ((unsigned long long)m * m) % (2ull * n);
+        const long double a = -pi * (long double)r / (long double)n;
+        c[m].re = (T)cosl(a);
+        c[m].im = (T)sinl(a);
+    }
+    return c;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+
+struct dspmi_fft_plan {
+    int device = 0;
+    int precision = 0;
+    unsigned n = 0;
+    int num_cu = 256;
+    size_t esz = 8;        // bytes per complex element
+    void *tw_n = nullptr;  // exp(-2 pi i k / n), k < n (c2c twiddles; also the r2c split factors)
+    void *tw_half = nullptr;
+    const dspmi::FftKernel *kern = nullptr;       // power-of-two n
+    const dspmi::FftKernel *kern_half = nullptr;  // n even with a power-of-two half
+    // Bluestein (any other n)
+    unsigned M = 0;
+    const dspmi::FftKernel *kern_M = nullptr;
+    void *tw_M = nullptr, *chirp = nullptr, *filt = nullptr;
+    // scratch, grown on demand (allocation happens in exec only when a batch outgrows it)
+    void *work[2] = {nullptr, nullptr};
+    size_t work_bytes[2] = {0, 0};
+    char name[64] = "";
+};
+
+namespace {
+
+int ensure_work(dspmi_fft_plan *pl, int which, size_t bytes)
+{
+    if (bytes <= pl->work_bytes[which]) return DSPMI_OK;
+    if (pl->work[which]) DSPMI_HIP(hipFree(pl->work[which]));
+    pl->work[which] = nullptr;
+    pl->work_bytes[which] = 0;
+    DSPMI_HIP(hipMalloc(&pl->work[which], bytes));
+    pl->work_bytes[which] = bytes;
+    return DSPMI_OK;
+}
+
+int run_pow2(const dspmi::FftKernel *k, const void *in, void *out, const void *tw, size_t batch, int backward, size_t esz,
+             int num_cu, hipStream_t s)
+{
+    // a batch that cannot stay in the 256 MiB last-level cache is a read-once / write-once
+    // stream: bypass the caches' allocation with nontemporal accesses
+    const bool stream_policy = batch * (size_t)k->n * esz >= ((size_t)256 << 20);
+    return (stream_policy ? k->fn_stream : k->fn)(in, out, tw, batch, backward, num_cu, s);
+}
+
+template <typename T>
+int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int backward, hipStream_t s)
+{
+    if (pl->kern) return run_pow2(pl->kern, in, out, pl->tw_n, batch, backward, pl->esz, pl->num_cu, s);
+    // Bluestein
+    const unsigned n = pl->n, M = pl->M;
+    int rc = ensure_work(pl, 0, batch * (size_t)M * sizeof(C<T>));
+    if (rc != DSPMI_OK) return rc;
+    C<T> *w = static_cast<C<T> *>(pl->work[0]);
+    hipLaunchKernelGGL(bluestein_pre_kernel<T>, dim3(ew_grid(batch * M, pl->num_cu)), dim3(256), 0, s,
+                       static_cast<const C<T> *>(in), static_cast<const C<T> *>(pl->chirp), w, n, M, batch, backward);
+    DSPMI_HIP(hipGetLastError());
+    rc = run_pow2(pl->kern_M, w, w, pl->tw_M, batch, 0, pl->esz, pl->num_cu, s);
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(bluestein_mul_kernel<T>, dim3(ew_grid(batch * M, pl->num_cu)), dim3(256), 0, s, w,
+                       static_cast<const C<T> *>(pl->filt), M, batch);
+    DSPMI_HIP(hipGetLastError());
+    rc = run_pow2(pl->kern_M, w, w, pl->tw_M, batch, 1, pl->esz, pl->num_cu, s);
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(bluestein_post_kernel<T>, dim3(ew_grid(batch * n, pl->num_cu)), dim3(256), 0, s, w,
+                       static_cast<const C<T> *>(pl->chirp), static_cast<C<T> *>(out), n, M, batch, backward);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+// filt = FFT_M(b) / M with b[m] = conj(c[m]) for |m| < n laid out circularly
+template <typename T>
+int setup_bluestein(dspmi_fft_plan *pl)
+{
+    const unsigned n = pl->n, M = pl->M;
+    std::vector<C<T>> c = chirp<T>(n);
+    std::vector<C<T>> b(M, C<T>{T(0), T(0)});
+    for (unsigned m = 0; m < n; m++) {
+        // chirp in full precision again for the filter, scaled by 1/M
+        const long double pi = 3.141592653589793238462643383279502884L;
+        const unsigned long long r = ((unsigned long long)m * m) % (2ull * n);
+        const long double a = pi * (long double)r / (long double)n;
+        const C<T> v = {(T)(cosl(a) / (long double)M), (T)(sinl(a) / (long double)M)};
+        b[m] = v;
+        if (m) b[M - m] = v;
+    }
+    int rc = upload<T>(&pl->chirp, c);
+    if (rc == DSPMI_OK) rc = upload<T>(&pl->filt, b);
+    if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_M, M, pl->precision);
+    if (rc == DSPMI_OK) rc = pl->kern_M->fn(pl->filt, pl->filt, pl->tw_M, 1, 0, pl->num_cu, nullptr);
+    if (rc == DSPMI_OK) DSPMI_HIP(hipStreamSynchronize(nullptr));
+    return rc;
+}
+
+template <typename T>
+int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipStream_t s)
+{
+    const unsigned n = pl->n;
+    if (n == 1) {
+        hipLaunchKernelGGL(real_to_complex_kernel<T>, dim3(ew_grid(batch, pl->num_cu)), dim3(256), 0, s,
+                           static_cast<const T *>(in), static_cast<C<T> *>(out), batch);
+        DSPMI_HIP(hipGetLastError());
+        return DSPMI_OK;
+    }
+    if (pl->kern_half) {
+        int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
+        if (rc != DSPMI_OK) return rc;
+        // the real frame [n] reinterpreted as n/2 complex points is the packed input
+        rc = run_pow2(pl->kern_half, in, pl->work[1], pl->tw_half, batch, 0, pl->esz, pl->num_cu, s);
+        if (rc != DSPMI_OK) return rc;
+        hipLaunchKernelGGL(r2c_split_kernel<T>, dim3(ew_grid(batch * (n / 2 + 1), pl->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<T> *>(pl->work[1]), static_cast<C<T> *>(out),
+                           static_cast<const C<T> *>(pl->tw_n), n, batch);
+        DSPMI_HIP(hipGetLastError());
+        return DSPMI_OK;
+    }
+    // any other length: complexify, full transform, keep bins 0..n/2
+    int rc = ensure_work(pl, 1, 2 * batch * (size_t)n * sizeof(C<T>));
+    if (rc != DSPMI_OK) return rc;
+    C<T> *za = static_cast<C<T> *>(pl->work[1]);
+    C<T> *zb = za + batch * (size_t)n;
+    hipLaunchKernelGGL(real_to_complex_kernel<T>, dim3(ew_grid(batch * n, pl->num_cu)), dim3(256), 0, s,
+                       static_cast<const T *>(in), za, batch * (size_t)n);
+    DSPMI_HIP(hipGetLastError());
+    rc = c2c_typed<T>(pl, za, zb, batch, 0, s);
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(take_bins_kernel<T>, dim3(ew_grid(batch * (n / 2 + 1), pl->num_cu)), dim3(256), 0, s, zb,
+                       static_cast<C<T> *>(out), n, batch);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+template <typename T>
+int c2r_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipStream_t s)
+{
+    const unsigned n = pl->n;
+    if (n == 1) {
+        hipLaunchKernelGGL(take_real_kernel<T>, dim3(ew_grid(batch, pl->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<T> *>(in), static_cast<T *>(out), batch);
+        DSPMI_HIP(hipGetLastError());
+        return DSPMI_OK;
+    }
+    if (pl->kern_half) {
+        int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
+        if (rc != DSPMI_OK) return rc;
+        hipLaunchKernelGGL(c2r_merge_kernel<T>, dim3(ew_grid(batch * (n / 2), pl->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<T> *>(in), static_cast<C<T> *>(pl->work[1]),
+                           static_cast<const C<T> *>(pl->tw_n), n, batch);
+        DSPMI_HIP(hipGetLastError());
+        return run_pow2(pl->kern_half, pl->work[1], out, pl->tw_half, batch, 1, pl->esz, pl->num_cu, s);
+    }
+    int rc = ensure_work(pl, 1, 2 * batch * (size_t)n * sizeof(C<T>));
+    if (rc != DSPMI_OK) return rc;
+    C<T> *za = static_cast<C<T> *>(pl->work[1]);
+    C<T> *zb = za + batch * (size_t)n;
+    hipLaunchKernelGGL(hermitian_extend_kernel<T>, dim3(ew_grid(batch * n, pl->num_cu)), dim3(256), 0, s,
+                       static_cast<const C<T> *>(in), za, n, batch);
+    DSPMI_HIP(hipGetLastError());
+    rc = c2c_typed<T>(pl, za, zb, batch, 1, s);
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(take_real_kernel<T>, dim3(ew_grid(batch * n, pl->num_cu)), dim3(256), 0, s, zb, static_cast<T *>(out),
+                       batch * (size_t)n);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+bool is_pow2(unsigned n) { return n && (n & (n - 1)) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
+{
+    if (!plan || n == 0) return dspmi::fail(DSPMI_EINVAL, "fft_create: null plan pointer or n == 0");
+    if (precision != DSPMI_F32 && precision != DSPMI_F64) return dspmi::fail(DSPMI_EINVAL, "fft_create: bad precision");
+    const char *pname = precision == DSPMI_F64 ? "f64" : "f32";
+    const dspmi::FftKernel *k = nullptr, *kh = nullptr, *kM = nullptr;
+    unsigned M = 0;
+    if (n > 1) {
+        if (is_pow2(n)) {
+            k = dspmi::fft_find(n, precision);
+            if (!k) return dspmi::fail(DSPMI_ENOSYS, "fft_create: no %s kernel for n = %u", pname, n);
+        } else {
+            M = 1;
+            while (M < 2 * n - 1) M <<= 1;
+            kM = dspmi::fft_find(M, precision);
+            if (!kM)
+                return dspmi::fail(DSPMI_ENOSYS, "fft_create: n = %u needs a %u-point %s transform, which no kernel covers",
+                                   n, M, pname);
+        }
+        if (n % 2 == 0 && n >= 4 && is_pow2(n / 2)) kh = dspmi::fft_find(n / 2, precision);
+    }
+    if (device < 0) DSPMI_HIP(hipGetDevice(&device));
+    int prev = 0;
+    DSPMI_HIP(hipGetDevice(&prev));
+    DSPMI_HIP(hipSetDevice(device));
+    dspmi_fft_plan *pl = new dspmi_fft_plan();
+    pl->device = device;
+    pl->precision = precision;
+    pl->n = n;
+    pl->esz = precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
+    pl->kern = k;
+    pl->kern_half = kh;
+    pl->kern_M = kM;
+    pl->M = M;
+    if (k) snprintf(pl->name, sizeof pl->name, "%s", k->name);
+    else if (kM) snprintf(pl->name, sizeof pl->name, "bluestein_n%u_via_%s", n, kM->name);
+    else snprintf(pl->name, sizeof pl->name, "fft_n1");
+    hipDeviceProp_t prop;
+    int rc = DSPMI_OK;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = dspmi::fail(DSPMI_EIO, "fft_create: hipGetDeviceProperties failed");
+    else pl->num_cu = prop.multiProcessorCount;
+    if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n, n, precision);
+    if (rc == DSPMI_OK && kh) rc = upload_twiddles(&pl->tw_half, n / 2, precision);
+    if (rc == DSPMI_OK && kM) rc = precision == DSPMI_F64 ? setup_bluestein<double>(pl) : setup_bluestein<float>(pl);
+    (void)hipSetDevice(prev);
+    if (rc != DSPMI_OK) {
+        dspmi_fft_destroy(pl);
+        return rc;
+    }
+    *plan = pl;
+    return DSPMI_OK;
+}
+
+int dspmi_fft_destroy(dspmi_fft_t plan)
+{
+    if (!plan) return DSPMI_OK;
+    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1]};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete plan;
+    return DSPMI_OK;
+}
+
+int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, int sign, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null plan");
+    if (sign != DSPMI_FORWARD && sign != DSPMI_BACKWARD) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: sign must be -1 or +1");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->n == 1) {
+        if (in != out) DSPMI_HIP(hipMemcpyAsync(out, in, batch * plan->esz, hipMemcpyDeviceToDevice, s));
+        return DSPMI_OK;
+    }
+    const int backward = sign == DSPMI_BACKWARD;
+    return plan->precision == DSPMI_F64 ? c2c_typed<double>(plan, in, out, batch, backward, s)
+                                        : c2c_typed<float>(plan, in, out, batch, backward, s);
+}
+
+int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null plan");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return plan->precision == DSPMI_F64 ? r2c_typed<double>(plan, in, out, batch, s) : r2c_typed<float>(plan, in, out, batch, s);
+}
+
+int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null plan");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return plan->precision == DSPMI_F64 ? c2r_typed<double>(plan, in, out, batch, s) : c2r_typed<float>(plan, in, out, batch, s);
+}
+
+const char *dspmi_fft_variant(dspmi_fft_t plan)
+{
+    return plan ? plan->name : "";
+}
+
+}  // extern "C"
+
+// Element-wise helpers used by the host wrappers.
+namespace dspmi {
+
+int bin_gain_f64(void *bins, const double *gain_dev, unsigned nbin, size_t batch, int num_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(bin_gain_kernel<double>, dim3(ew_grid(batch * nbin, num_cu)), dim3(256), 0, s,
+                       static_cast<C<double> *>(bins), gain_dev, nbin, batch);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride, hipStream_t s)
+{
+    hipLaunchKernelGGL(ps_abs_kernel<double>, dim3(ew_grid(batch * nout, 256)), dim3(256), 0, s,
+                       static_cast<const C<double> *>(bins), out, nout, scale, batch, in_stride);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int scale_f64(double *x, double divisor, size_t total, int num_cu, hipStream_t s)
+{
+    hipLaunchKernelGGL(scale_kernel<double>, dim3(ew_grid(total, num_cu)), dim3(256), 0, s, x, divisor, total);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+}  // namespace dspmi

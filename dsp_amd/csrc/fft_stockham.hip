@@ -20,6 +20,7 @@
 // (fftc/main.c:31-43): unnormalised in both directions, sign -1 forward.
 // The backward transform is conj(forward(conj(x))).
 #include "common.h"
+#include "fft_internal.h"
 
 #include <cmath>
 #include <cstdint>
@@ -325,119 +326,8 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
 }
 
 // ---------------------------------------------------------------------------
-// real <-> half-complex helpers (length n even): one complex FFT of n/2 points
-// plus an O(n) split / merge step.
+// launchers and the kernel table
 // ---------------------------------------------------------------------------
-
-// Z = FFT_{n/2}(x[2m] + i x[2m+1]);  X[k] = E[k] + W_n^k O[k], k = 0..n/2, with
-// E[k] = (Z[k] + conj Z[h-k])/2, O[k] = -i (Z[k] - conj Z[h-k])/2, h = n/2, Z[h] = Z[0].
-template <typename T>
-__global__ __launch_bounds__(256) void r2c_split_kernel(const C<T> *__restrict__ z, C<T> *__restrict__ xout,
-                                                        const C<T> *__restrict__ twn, unsigned n, size_t batch)
-{
-    const unsigned h = n / 2;
-    const size_t total = batch * (size_t)(h + 1);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t f = i / (h + 1);
-        const unsigned k = (unsigned)(i - f * (h + 1));
-        const C<T> *zf = z + f * h;
-        const C<T> a = zf[k == h ? 0 : k];
-        const C<T> b0 = zf[(h - k) % h];
-        const C<T> b = {b0.re, -b0.im};
-        const C<T> e = {(a.re + b.re) * T(0.5), (a.im + b.im) * T(0.5)};
-        const C<T> d = {(a.re - b.re) * T(0.5), (a.im - b.im) * T(0.5)};
-        const C<T> o = {d.im, -d.re};  // -i * d
-        const C<T> w = (k == h) ? C<T>{T(-1), T(0)} : twn[k];  // exp(-2 pi i k / n)
-        const C<T> wo = cmul(w, o);
-        xout[f * (h + 1) + k] = {e.re + wo.re, e.im + wo.im};
-    }
-}
-
-// Inverse of the split, unnormalised c2r: x = IFFT_n(Hermitian X) (scale n) equals the
-// n/2-point backward transform of Z[k] = (X[k] + conj X[h-k]) + i W_n^{-k} (X[k] - conj X[h-k]).
-template <typename T>
-__global__ __launch_bounds__(256) void c2r_merge_kernel(const C<T> *__restrict__ xin, C<T> *__restrict__ z,
-                                                        const C<T> *__restrict__ twn, unsigned n, size_t batch)
-{
-    const unsigned h = n / 2;
-    const size_t total = batch * (size_t)h;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t f = i / h;
-        const unsigned k = (unsigned)(i - f * h);
-        const C<T> *xf = xin + f * (h + 1);
-        C<T> a = xf[k];
-        C<T> b0 = xf[h - k];
-        // like FFTW's c2r, ignore the imaginary parts of the DC and Nyquist bins
-        if (k == 0) { a.im = T(0); b0.im = T(0); }
-        const C<T> b = {b0.re, -b0.im};
-        const C<T> s = {a.re + b.re, a.im + b.im};
-        const C<T> d = {a.re - b.re, a.im - b.im};
-        const C<T> w0 = twn[k];
-        const C<T> w = {w0.re, -w0.im};  // exp(+2 pi i k / n)
-        const C<T> wd = cmul(w, d);
-        z[f * h + k] = {s.re - wd.im, s.im + wd.re};  // s + i * wd
-    }
-}
-
-// out[f][k] = in[f][k] * g[k]  (real gain per bin; util/filter/filter.c:92-96)
-template <typename T>
-__global__ __launch_bounds__(256) void bin_gain_kernel(C<T> *__restrict__ bins, const T *__restrict__ g,
-                                                       unsigned nbin, size_t batch)
-{
-    const size_t total = batch * (size_t)nbin;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const T gg = g[i % nbin];
-        C<T> v = bins[i];
-        v.re *= gg;
-        v.im *= gg;
-        bins[i] = v;
-    }
-}
-
-// out[f][i] = 2*|bins[f][i]| / scale, i < nout (fftc/main.c:80-105, fir/src/main.c:246-251)
-template <typename T>
-__global__ __launch_bounds__(256) void ps_abs_kernel(const C<T> *__restrict__ bins, T *__restrict__ out, unsigned nout,
-                                                     T scale, size_t batch, unsigned in_stride)
-{
-    const size_t total = batch * (size_t)nout;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t f = i / nout;
-        const C<T> v = bins[f * in_stride + (i - f * nout)];
-        out[i] = (T(2) * sqrt(v.re * v.re + v.im * v.im)) / scale;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void scale_kernel(T *__restrict__ x, T divisor, size_t total)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-        x[i] = x[i] / divisor;
-}
-
-}  // namespace
-
-// ---------------------------------------------------------------------------
-// plan
-// ---------------------------------------------------------------------------
-
-typedef int (*fft_launch_fn)(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu,
-                             hipStream_t s);
-
-struct dspmi_fft_plan {
-    int device;
-    int precision;
-    unsigned n;
-    int num_cu;
-    void *tw_n;       // exp(-2 pi i k / n), k < n (c2c twiddles; also the r2c split factors)
-    void *tw_half;    // exp(-2 pi i k / (n/2)) for the half-length transform of r2c / c2r (n even)
-    void *work;       // scratch for r2c / c2r: batch_cap * (n/2) complex
-    size_t work_cap;  // in frames
-    fft_launch_fn launch, launch_stream;
-    fft_launch_fn launch_half, launch_half_stream;
-    char name[64];
-};
-
-namespace {
 
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
@@ -482,12 +372,7 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     return DSPMI_OK;
 }
 
-struct FftEntry {
-    unsigned n;
-    fft_launch_fn fn;         // default cache policy
-    fft_launch_fn fn_stream;  // nontemporal loads and stores: batches far larger than the caches
-    const char *name;
-};
+typedef dspmi::FftKernel FftEntry;
 
 // f32: twiddles in a per-workgroup LDS table (registers stay free for the butterflies: 4 waves
 // per SIMD instead of 2); f64: twiddles read from the global table through L1.
@@ -536,197 +421,10 @@ const FftEntry *find_entry(unsigned n, int precision)
     return nullptr;
 }
 
-template <typename T>
-int upload_twiddles(void **dev, unsigned n)
-{
-    std::vector<C<T>> tw(n);
-    const long double two_pi = 6.283185307179586476925286766559005768L;
-    for (unsigned k = 0; k < n; k++) {
-        const long double a = -two_pi * (long double)k / (long double)n;
-        tw[k].re = (T)cosl(a);
-        tw[k].im = (T)sinl(a);
-    }
-    DSPMI_HIP(hipMalloc(dev, n * sizeof(C<T>)));
-    DSPMI_HIP(hipMemcpy(*dev, tw.data(), n * sizeof(C<T>), hipMemcpyHostToDevice));
-    return DSPMI_OK;
-}
-
-int ensure_work(dspmi_fft_plan *pl, size_t batch)
-{
-    if (batch <= pl->work_cap) return DSPMI_OK;
-    if (pl->work) DSPMI_HIP(hipFree(pl->work));
-    pl->work = nullptr;
-    pl->work_cap = 0;
-    const size_t esz = pl->precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
-    DSPMI_HIP(hipMalloc(&pl->work, batch * (size_t)(pl->n / 2) * esz));
-    pl->work_cap = batch;
-    return DSPMI_OK;
-}
-
-inline unsigned ew_grid(size_t total, int num_cu)
-{
-    size_t g = (total + 255) / 256;
-    const size_t cap = (size_t)num_cu * 8;
-    return (unsigned)(g < cap ? (g ? g : 1) : cap);
-}
-
 }  // namespace
 
-extern "C" {
-
-int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
-{
-    if (!plan || n == 0) return dspmi::fail(DSPMI_EINVAL, "fft_create: null plan pointer or n == 0");
-    if (precision != DSPMI_F32 && precision != DSPMI_F64) return dspmi::fail(DSPMI_EINVAL, "fft_create: bad precision");
-    const FftEntry *e = n == 1 ? nullptr : find_entry(n, precision);
-    const FftEntry *eh = (n % 2 == 0 && n >= 4) ? find_entry(n / 2, precision) : nullptr;
-    if (!e && !eh && n != 1)
-        return dspmi::fail(DSPMI_ENOSYS, "fft_create: no kernel for n = %u (%s)", n, precision == DSPMI_F64 ? "f64" : "f32");
-    if (device < 0) DSPMI_HIP(hipGetDevice(&device));
-    int prev = 0;
-    DSPMI_HIP(hipGetDevice(&prev));
-    DSPMI_HIP(hipSetDevice(device));
-    dspmi_fft_plan *pl = new dspmi_fft_plan();
-    pl->device = device;
-    pl->precision = precision;
-    pl->n = n;
-    pl->launch = e ? e->fn : nullptr;
-    pl->launch_stream = e ? e->fn_stream : nullptr;
-    pl->launch_half = eh ? eh->fn : nullptr;
-    pl->launch_half_stream = eh ? eh->fn_stream : nullptr;
-    snprintf(pl->name, sizeof pl->name, "%s", e ? e->name : (eh ? eh->name : "fft_n1"));
-    hipDeviceProp_t prop;
-    int rc = DSPMI_OK;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = dspmi::fail(DSPMI_EIO, "fft_create: hipGetDeviceProperties failed");
-    pl->num_cu = rc == DSPMI_OK ? prop.multiProcessorCount : 256;
-    if (rc == DSPMI_OK)
-        rc = precision == DSPMI_F64 ? upload_twiddles<double>(&pl->tw_n, n) : upload_twiddles<float>(&pl->tw_n, n);
-    if (rc == DSPMI_OK && eh)
-        rc = precision == DSPMI_F64 ? upload_twiddles<double>(&pl->tw_half, n / 2) : upload_twiddles<float>(&pl->tw_half, n / 2);
-    (void)hipSetDevice(prev);
-    if (rc != DSPMI_OK) {
-        dspmi_fft_destroy(pl);
-        return rc;
-    }
-    *plan = pl;
-    return DSPMI_OK;
-}
-
-int dspmi_fft_destroy(dspmi_fft_t plan)
-{
-    if (!plan) return DSPMI_OK;
-    if (plan->tw_n) (void)hipFree(plan->tw_n);
-    if (plan->tw_half) (void)hipFree(plan->tw_half);
-    if (plan->work) (void)hipFree(plan->work);
-    delete plan;
-    return DSPMI_OK;
-}
-
-int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, int sign, void *stream)
-{
-    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null plan");
-    if (sign != DSPMI_FORWARD && sign != DSPMI_BACKWARD) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: sign must be -1 or +1");
-    if (batch == 0) return DSPMI_OK;
-    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null buffer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (plan->n == 1) {
-        if (in != out) {
-            const size_t esz = plan->precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
-            DSPMI_HIP(hipMemcpyAsync(out, in, batch * esz, hipMemcpyDeviceToDevice, s));
-        }
-        return DSPMI_OK;
-    }
-    if (!plan->launch) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_c2c: no complex kernel for n = %u", plan->n);
-    // a batch that cannot stay in the 256 MiB last-level cache is a read-once / write-once
-    // stream: bypass the caches' allocation with nontemporal accesses
-    const size_t esz = plan->precision == DSPMI_F64 ? sizeof(C<double>) : sizeof(C<float>);
-    const bool stream_policy = batch * (size_t)plan->n * esz >= ((size_t)256 << 20);
-    return (stream_policy ? plan->launch_stream : plan->launch)(in, out, plan->tw_n, batch, sign == DSPMI_BACKWARD,
-                                                                plan->num_cu, s);
-}
-
-int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
-{
-    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null plan");
-    if (batch == 0) return DSPMI_OK;
-    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null buffer");
-    if (plan->n % 2 || !plan->launch_half)
-        return dspmi::fail(DSPMI_ENOSYS, "fft_exec_r2c: n = %u needs an even length with a half-length kernel", plan->n);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = ensure_work(plan, batch);
-    if (rc != DSPMI_OK) return rc;
-    // the real frame [n] reinterpreted as n/2 complex points is the packed input
-    rc = plan->launch_half(in, plan->work, plan->tw_half, batch, 0, plan->num_cu, s);
-    if (rc != DSPMI_OK) return rc;
-    const size_t total = batch * (size_t)(plan->n / 2 + 1);
-    if (plan->precision == DSPMI_F64)
-        hipLaunchKernelGGL(r2c_split_kernel<double>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
-                           static_cast<const C<double> *>(plan->work), static_cast<C<double> *>(out),
-                           static_cast<const C<double> *>(plan->tw_n), plan->n, batch);
-    else
-        hipLaunchKernelGGL(r2c_split_kernel<float>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
-                           static_cast<const C<float> *>(plan->work), static_cast<C<float> *>(out),
-                           static_cast<const C<float> *>(plan->tw_n), plan->n, batch);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
-int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
-{
-    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null plan");
-    if (batch == 0) return DSPMI_OK;
-    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null buffer");
-    if (plan->n % 2 || !plan->launch_half)
-        return dspmi::fail(DSPMI_ENOSYS, "fft_exec_c2r: n = %u needs an even length with a half-length kernel", plan->n);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = ensure_work(plan, batch);
-    if (rc != DSPMI_OK) return rc;
-    const size_t total = batch * (size_t)(plan->n / 2);
-    if (plan->precision == DSPMI_F64)
-        hipLaunchKernelGGL(c2r_merge_kernel<double>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
-                           static_cast<const C<double> *>(in), static_cast<C<double> *>(plan->work),
-                           static_cast<const C<double> *>(plan->tw_n), plan->n, batch);
-    else
-        hipLaunchKernelGGL(c2r_merge_kernel<float>, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
-                           static_cast<const C<float> *>(in), static_cast<C<float> *>(plan->work),
-                           static_cast<const C<float> *>(plan->tw_n), plan->n, batch);
-    DSPMI_HIP(hipGetLastError());
-    return plan->launch_half(plan->work, out, plan->tw_half, batch, 1, plan->num_cu, s);
-}
-
-const char *dspmi_fft_variant(dspmi_fft_t plan)
-{
-    return plan ? plan->name : "";
-}
-
-}  // extern "C"
-
-// Element-wise helpers used by the host wrappers (same translation unit so the
-// kernels above stay file-local).
 namespace dspmi {
 
-int bin_gain_f64(void *bins, const double *gain_dev, unsigned nbin, size_t batch, int num_cu, hipStream_t s)
-{
-    hipLaunchKernelGGL(bin_gain_kernel<double>, dim3(ew_grid(batch * nbin, num_cu)), dim3(256), 0, s,
-                       static_cast<C<double> *>(bins), gain_dev, nbin, batch);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
-int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride,
-               hipStream_t s)
-{
-    hipLaunchKernelGGL(ps_abs_kernel<double>, dim3(ew_grid(batch * nout, 256)), dim3(256), 0, s,
-                       static_cast<const C<double> *>(bins), out, nout, scale, batch, in_stride);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
-int scale_f64(double *x, double divisor, size_t total, int num_cu, hipStream_t s)
-{
-    hipLaunchKernelGGL(scale_kernel<double>, dim3(ew_grid(total, num_cu)), dim3(256), 0, s, x, divisor, total);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
+const FftKernel *fft_find(unsigned n, int precision) { return find_entry(n, precision); }
 
 }  // namespace dspmi

@@ -1,0 +1,75 @@
+"""The C demos (demos/*.c: the reference's mains over include/dsp_dropin.h) build with
+gcc, and on the GPU print what the reference prints."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "demos", "bin")
+
+
+def _build():
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "demos")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_demos_compile_as_plain_c():
+    _build()
+    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo"):
+        assert os.path.exists(os.path.join(BIN, name))
+
+
+def _run(name):
+    _build()
+    r = subprocess.run([os.path.join(BIN, name)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+@pytest.mark.gpu
+def test_convolution_demo_prints_the_reference_table(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "conv_kat9.json")))
+    want = "".join("%u %f %f %f\n" % (i, kat["x"][i], kat["y0"][i], kat["y1"][i]) for i in range(9))
+    assert _run("convolution_demo") == want
+    rows = [ln.split() for ln in want.splitlines()]
+    assert [float(r[2]) for r in rows] == kat["y0_printed"] and [float(r[3]) for r in rows] == kat["y1_printed"]
+
+
+@pytest.mark.gpu
+def test_fir_demo_matches_oracle_text(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tone_fir.npz"))
+    want = "".join("%f %f %f\n" % (i / 48000.0, g["y16"][i], g["tone"][i]) for i in range(1000))
+    assert _run("fir_demo") == want
+
+
+@pytest.mark.gpu
+def test_filter_demo_matches_oracle():
+    t = oracle.Tonegen()
+    t.add(48000.0, 1000.0, 1.0, 0.0)
+    t.add(48000.0, 12000.0, 0.5, 0.3)
+    x = t.read(4096)
+    fres = 48000.0 / 4096
+    f = np.arange(2049) * fres
+    coeffs = np.where(f < 3000, 1.0, np.where(f < 3500, 0.5, 0.0))
+    want = oracle.filter(x, coeffs)
+    rows = np.array([[float(v) for v in ln.split()] for ln in _run("filter_demo").splitlines()])
+    assert rows.shape == (4096, 3)
+    np.testing.assert_allclose(rows[:, 1], x, atol=6e-7)
+    np.testing.assert_allclose(rows[:, 2], want, atol=6e-7)
+
+
+@pytest.mark.gpu
+def test_fftc_demo_matches_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "fft_cases.npz"))
+    y = g["fftc_y"]
+    rows = np.array([[float(v) for v in ln.split()] for ln in _run("fftc_demo").splitlines()])
+    assert rows.shape == (240, 5)
+    np.testing.assert_allclose(rows[:, 0], 100.0 * np.arange(240), atol=1e-6)
+    np.testing.assert_allclose(rows[:, 1], oracle.ps_abs(y), atol=2e-6)
+    np.testing.assert_allclose(rows[:, 2], y.real[:240] / 240, atol=2e-6)
+    np.testing.assert_allclose(rows[:, 3], -y.imag[:240] / 240, atol=2e-6)

@@ -129,3 +129,45 @@ def test_double_wrappers(golden_dir):
     assert rel_l2(dsp_amd.filter(x, np.ones(2049)), x) <= TOL_F64
     z = g["in_1024"]
     assert rel_l2(dsp_amd.fft_mag(z), oracle.ps_abs(g["fwd_1024"])) <= TOL_F64
+
+
+# ---- lengths that are not powers of two (Bluestein) ------------------------------
+
+@pytest.mark.parametrize("n", [3, 5, 12, 100, 480, 482, 1000, 3000])
+def test_c2c_any_length_f32(n):
+    rng = np.random.default_rng(n)
+    z = (rng.uniform(-1, 1, (4, n)) + 1j * rng.uniform(-1, 1, (4, n))).astype(np.complex64)
+    plan = dsp_amd.FftPlan(n, "f32")
+    assert "bluestein" in plan.variant
+    zd = torch.from_numpy(z).cuda()
+    fwd = plan.c2c(zd, dsp_amd.FORWARD).cpu().numpy()
+    bwd = plan.c2c(zd, dsp_amd.BACKWARD).cpu().numpy()
+    for f in range(4):
+        zz = z[f].astype(np.complex128)
+        assert rel_l2(fwd[f], oracle.dft(zz, -1, "direct")) <= TOL_FFT
+        assert rel_l2(bwd[f], oracle.dft(zz, +1, "direct")) <= TOL_FFT
+
+
+def test_demo_lengths_double_wrappers(golden_dir):
+    """480 (fftc/main.c:137) and 482 (fir/src/main.c:154) through dft/idft."""
+    g = np.load(os.path.join(golden_dir, "fft_cases.npz"))
+    for n in (480, 482):
+        z = g["in_%d" % n]
+        assert rel_l2(dsp_amd.dft(z), g["fwd_%d" % n]) <= 1e-12
+        assert rel_l2(dsp_amd.idft(z), g["bwd_%d" % n]) <= 1e-12
+    # the fftc demo's own data: forward, then backward / nx gives the input back
+    x = g["fftc_x"]
+    y = dsp_amd.dft(x)
+    assert rel_l2(y, g["fftc_y"]) <= 1e-12
+    assert rel_l2(dsp_amd.idft(y) / 480, x) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [6, 9, 100, 481, 1000, 3000])
+def test_real_transforms_any_length(n):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, n)
+    bins = dsp_amd.fft_r2c(x)
+    assert rel_l2(bins, oracle.fft_r2c(x)) <= 1e-12
+    gains = rng.uniform(0, 1, n // 2 + 1)
+    assert rel_l2(dsp_amd.filter(x, gains), oracle.filter(x, gains)) <= 1e-12
+    assert rel_l2(dsp_amd.filter(x, np.ones(n // 2 + 1)), x) <= 1e-12
