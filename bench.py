@@ -44,10 +44,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir16"])
+    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir16", "fir8191", "ols8191"])
     ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
+    ap.add_argument("--long-samples", type=int, default=1 << 26, help="samples of the single long signal (8191-tap workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     return ap.parse_args()
@@ -142,6 +143,27 @@ def make_fir(args, rank, nh):
                 samples_per_unit=1,
                 workload="batched FIR, %d taps, %d channels x %d samples per GPU" % (nh, args.channels, args.samples))
     return (lambda: plan.exec(x, args.samples, y=y)), info, (plan, x, y)
+
+
+def make_long(args, rank, use_ols):
+    """BASELINE config 4: one long real signal, 8191 taps, direct MFMA kernel vs overlap-save."""
+    nh = 8191
+    taps = sinc_taps(nh)
+    x = uniform((1, args.long_samples), 0xD5B0 + 4 + rank, "cuda")
+    y = torch.empty_like(x)
+    if use_ols:
+        plan = dsp_amd.OlsPlan(taps)
+        kernel = "ols_fft%d" % plan.fft_length
+        fn = lambda: plan.exec(x, y=y)
+    else:
+        plan = dsp_amd.FirPlan(taps, "f32")
+        kernel = plan.variant
+        fn = lambda: plan.exec(x, args.long_samples, y=y)
+    info = dict(kernel=kernel, units=args.long_samples, unit_name="samples", nh=nh,
+                flop_per_unit=2.0 * nh, bytes_per_unit=8.0, bound="hbm" if use_ols else "fp32", samples_per_unit=1,
+                workload="one %d-sample signal, %d taps, %s" % (args.long_samples, nh,
+                                                                "overlap-save" if use_ols else "direct"))
+    return fn, info, (plan, x, y)
 
 
 def measured_traffic(info):
@@ -239,6 +261,9 @@ def main():
 
     if args.workload == "fft1024":
         fn, info, keep = make_fft(args, rank)
+    elif args.workload in ("fir8191", "ols8191"):
+        fn, info, keep = make_long(args, rank, args.workload == "ols8191")
+        args.no_secondary = True
     else:
         fn, info, keep = make_fir(args, rank, 127 if args.workload == "fir127" else 16)
 

@@ -25,6 +25,7 @@ SOURCES = {
     "fir_direct.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"],
     "fft_stockham.hip": [],
     "fft_plan.hip": [],
+    "ols.hip": [],
     "wrappers.cpp": ["-x", "hip"],
 }
 

@@ -51,6 +51,10 @@ _SIGS = {
     "dspmi_fft_exec_r2c": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "dspmi_fft_exec_c2r": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "dspmi_fft_variant": (C.c_char_p, [_vp]),
+    "dspmi_ols_create_f32": (C.c_int, [C.POINTER(_vp), _fp, _u, _u, C.c_int]),
+    "dspmi_ols_destroy": (C.c_int, [_vp]),
+    "dspmi_ols_fft_length": (_u, [_vp]),
+    "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),
@@ -203,6 +207,47 @@ class FftPlan:
     def close(self):
         if self._h:
             lib().dspmi_fft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OlsPlan:
+    """Overlap-save fast convolution for long filters (f32); same result as FirPlan.exec(x, nx)."""
+
+    def __init__(self, taps, fft_n=0, device=-1):
+        self.nh = len(taps)
+        self._h = C.c_void_p()
+        t = np.ascontiguousarray(taps, dtype=np.float32)
+        _check(lib().dspmi_ols_create_f32(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, fft_n, device), "ols_create")
+
+    @property
+    def fft_length(self):
+        return lib().dspmi_ols_fft_length(self._h)
+
+    def exec(self, x, y=None, hist=None):
+        import torch
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        nchan, nx = x.shape
+        if y is None:
+            y = torch.empty((nchan, nx), dtype=torch.float32, device=x.device)
+        assert y.is_cuda and y.dtype == torch.float32 and y.shape == (nchan, nx) and y.stride(1) == 1
+        hp, hs = None, 0
+        if hist is not None:
+            assert hist.is_cuda and hist.dtype == torch.float32 and hist.shape == (nchan, self.nh - 1) and hist.stride(1) == 1
+            hp, hs = hist.data_ptr(), hist.stride(0) if nchan > 1 else self.nh - 1
+        _check(lib().dspmi_ols_exec_f32(self._h, y.data_ptr(), y.stride(0) if nchan > 1 else nx,
+                                        x.data_ptr(), x.stride(0) if nchan > 1 else nx, nx, nchan, hp, hs, _stream()),
+               "ols_exec")
+        return y
+
+    def close(self):
+        if self._h:
+            lib().dspmi_ols_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -142,6 +142,27 @@ int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch
 const char *dspmi_fft_variant(dspmi_fft_t plan);
 
 /* ------------------------------------------------------------------------ */
+/* Overlap-save fast convolution (long filters)                              */
+/* ------------------------------------------------------------------------ */
+
+/* The FFT-domain form of the same FIR sum, for filters long enough that 2*nh
+ * flops per output cost more than two transforms: forward FFT, multiply by the
+ * taps' spectrum, backward FFT, divide by n -- the single-block scheme of
+ * util/filter/filter.c:73-105 (named as the scalable alternative in
+ * doc/notes:81-82) applied to overlapping blocks.  A plan holds H = FFT(taps)/N. */
+typedef struct dspmi_ols_plan *dspmi_ols_t;
+
+/* fft_n: transform length (power of two >= 2*nh, <= 16384), or 0 to choose. */
+int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsigned fft_n, int device);
+int dspmi_ols_destroy(dspmi_ols_t plan);
+unsigned dspmi_ols_fft_length(dspmi_ols_t plan);
+
+/* y[c][i] = sum_j h[j] * x[c][i-j], 0 <= i < nx: the same result as
+ * dspmi_fir_exec_f32 with nxx = nx (same history / stride arguments). */
+int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float *x, size_t x_stride,
+                       unsigned nx, unsigned nchan, const float *hist, size_t hist_stride, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Host drop-in wrappers (reference signatures; host double buffers)         */
 /* ------------------------------------------------------------------------ */
 
