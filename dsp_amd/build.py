@@ -26,6 +26,7 @@ SOURCES = {
     "fft_stockham.hip": [],
     "fft_plan.hip": [],
     "ols.hip": [],
+    "spectrum.hip": [],
     "wrappers.cpp": ["-x", "hip"],
 }
 

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
         if (d.plain) {
 #pragma unroll
             for (int it = 0; it < NIT; it++)
-                if (it < NIT - 1 || (int)(t + 256 * it) < d.nstage) xs[l0 + 16 * kRow * it] = stage[it];
+                if ((int)(t + 256 * it) < d.nstage) xs[l0 + 16 * kRow * it] = stage[it];
         } else {
             for (int l = t; l < d.nstage; l += 256) {
                 const long s = d.sbase + l;

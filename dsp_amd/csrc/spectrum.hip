@@ -1,0 +1,191 @@
+// Spectrum post-ops and the tone generator: the cheap stages either side of the FIR / FFT
+// kernels in the reference's real-time chain (alsa/main.c:542-568: spectrum, FIR, spectrum).
+//
+//  * power spectrum: |X[k]| per bin and one sum per frame, then the reference's
+//    normalisation -- fft_to_power_spectrum (fft/src/main.c:120-141: divide by the sum when
+//    it exceeds 1e-5), do_power_spectrum (alsa/main.c:473-487: always divide),
+//    ps_abs (fftc/main.c:80-105: 2|X|/n, no sum).  One wave per frame; the bins stay in
+//    registers between the magnitude pass and the divide.
+//  * tone generator: sum of a*cos(w+phi) with the running-phase recurrence w += dw of
+//    tonegen/tonegen.c:25-40, kept in double so a stream continues exactly where the last
+//    chunk stopped.  The recurrence is sequential in time, so the parallelism is over
+//    channels: one lane per channel, 64 samples at a time, transposed through LDS so that
+//    the stores to the channel-major signal are coalesced.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+struct alignas(8) C32 {
+    float re, im;
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+constexpr int kMaxPerLane = 64;  // up to 4096 bins per frame in registers
+
+// mode 0: ps = |X| / sum if sum > 1e-5 else |X|      (fft/src/main.c:120-141)
+// mode 1: ps = |X| / sum                             (alsa/main.c:473-487)
+// mode 2: ps = 2|X| / scale                          (fftc/main.c:80-105)
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void power_spectrum_kernel(float *__restrict__ ps, const C32 *__restrict__ bins,
+                                                             unsigned nbin, unsigned in_stride, size_t batch, int mode,
+                                                             float scale)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t f = wave; f < batch; f += nwaves) {
+        const C32 *src = bins + f * in_stride;
+        float mag[PER_LANE];
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < PER_LANE; q++) {
+            const unsigned k = lane + 64 * q;
+            float m = 0.f;
+            if (k < nbin) {
+                const C32 v = src[k];
+                m = sqrtf(v.re * v.re + v.im * v.im);
+            }
+            mag[q] = m;
+            part += m;
+        }
+        float div = 1.f, mul = 1.f;
+        if (mode == 2) {
+            mul = 2.f;
+            div = scale;
+        } else {
+            const float sum = wave_sum(part);
+            if (mode == 1 || sum > 0.00001f) div = sum;
+        }
+#pragma unroll
+        for (int q = 0; q < PER_LANE; q++) {
+            const unsigned k = lane + 64 * q;
+            if (k < nbin) ps[f * nbin + k] = (mul * mag[q]) / div;
+        }
+    }
+}
+
+// Frames too long for the register path: two passes over the bins.
+__global__ __launch_bounds__(256) void power_spectrum_long_kernel(float *__restrict__ ps, const C32 *__restrict__ bins,
+                                                                  unsigned nbin, unsigned in_stride, size_t batch, int mode,
+                                                                  float scale)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t f = wave; f < batch; f += nwaves) {
+        const C32 *src = bins + f * in_stride;
+        float part = 0.f;
+        for (unsigned k = lane; k < nbin; k += 64) {
+            const C32 v = src[k];
+            part += sqrtf(v.re * v.re + v.im * v.im);
+        }
+        float div = 1.f, mul = 1.f;
+        if (mode == 2) {
+            mul = 2.f;
+            div = scale;
+        } else {
+            const float sum = wave_sum(part);
+            if (mode == 1 || sum > 0.00001f) div = sum;
+        }
+        for (unsigned k = lane; k < nbin; k += 64) {
+            const C32 v = src[k];
+            ps[f * nbin + k] = (mul * sqrtf(v.re * v.re + v.im * v.im)) / div;
+        }
+    }
+}
+
+// state: [nchan][ntone] running angles (double, updated); dw, amp, phi: [nchan][ntone].
+// 64 channels per workgroup of 64 lanes; each lane advances its channel 64 samples, the
+// tile is transposed through LDS and written as 64 rows of 256 contiguous bytes.
+__global__ __launch_bounds__(64) void tonegen_kernel(float *__restrict__ x, size_t x_stride, unsigned n, unsigned nchan,
+                                                     unsigned ntone, double *__restrict__ w, const double *__restrict__ dw,
+                                                     const double *__restrict__ amp, const double *__restrict__ phi,
+                                                     int use_sin)
+{
+    __shared__ float tile[64][65];
+    const unsigned lane = threadIdx.x;
+    const unsigned c = blockIdx.x * 64 + lane;
+    const bool live = c < nchan;
+    constexpr int MAXT = 8;
+    double wl[MAXT], dwl[MAXT], al[MAXT], pl[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; j++) {
+        const bool on = live && j < (int)ntone;
+        wl[j] = on ? w[(size_t)c * ntone + j] : 0.0;
+        dwl[j] = on ? dw[(size_t)c * ntone + j] : 0.0;
+        al[j] = on ? amp[(size_t)c * ntone + j] : 0.0;
+        pl[j] = on ? phi[(size_t)c * ntone + j] : 0.0;
+    }
+    for (unsigned base = 0; base < n; base += 64) {
+        for (unsigned i = 0; i < 64; i++) {
+            // buf[i] = 0; buf[i] += a*cos(w + phi); w += dw  -- tones in order, in double
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < MAXT; j++) {
+                if (j < (int)ntone) {
+                    v += use_sin ? sin(wl[j]) : al[j] * cos(wl[j] + pl[j]);
+                    if (base + i < n) wl[j] += dwl[j];
+                }
+            }
+            tile[lane][i] = (float)v;
+        }
+        __syncthreads();
+        for (unsigned r = 0; r < 64; r++) {
+            const unsigned cc = blockIdx.x * 64 + r;
+            if (cc < nchan && base + lane < n) x[(size_t)cc * x_stride + base + lane] = tile[r][lane];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < MAXT; j++)
+        if (live && j < (int)ntone) w[(size_t)c * ntone + j] = wl[j];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigned in_stride, size_t batch, int mode,
+                             float scale, void *stream)
+{
+    if (batch == 0 || nbin == 0) return DSPMI_OK;
+    if (!ps || !bins) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: null buffer");
+    if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: mode must be 0, 1 or 2");
+    if (in_stride < nbin) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: in_stride < nbin");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    size_t blocks = (batch + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const C32 *b = static_cast<const C32 *>(bins);
+    if (nbin <= 64 * 8)
+        hipLaunchKernelGGL(power_spectrum_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, ps, b, nbin, in_stride, batch, mode, scale);
+    else if (nbin <= 64 * 33)
+        hipLaunchKernelGGL(power_spectrum_kernel<33>, dim3((unsigned)blocks), dim3(256), 0, s, ps, b, nbin, in_stride, batch, mode, scale);
+    else
+        hipLaunchKernelGGL(power_spectrum_long_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ps, b, nbin, in_stride, batch, mode, scale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
+                      const double *amp, const double *phi, int use_sin, void *stream)
+{
+    if (n == 0 || nchan == 0) return DSPMI_OK;
+    if (!x || !w || !dw || (!use_sin && (!amp || !phi))) return dspmi::fail(DSPMI_EINVAL, "tonegen: null buffer");
+    if (ntone == 0 || ntone > 8) return dspmi::fail(DSPMI_ENOSYS, "tonegen: 1..8 tones per channel on the device (got %u)", ntone);
+    if (x_stride < n) return dspmi::fail(DSPMI_EINVAL, "tonegen: x_stride < n");
+    if (use_sin && (!amp || !phi)) amp = phi = dw;  // never read in the sine form
+    hipLaunchKernelGGL(tonegen_kernel, dim3((nchan + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), x, x_stride, n,
+                       nchan, ntone, w, dw, amp, phi, use_sin);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+}  // extern "C"

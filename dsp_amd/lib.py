@@ -55,6 +55,8 @@ _SIGS = {
     "dspmi_ols_destroy": (C.c_int, [_vp]),
     "dspmi_ols_fft_length": (_u, [_vp]),
     "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
+    "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
+    "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),
@@ -214,6 +216,50 @@ class FftPlan:
             self.close()
         except Exception:
             pass
+
+
+PS_NORM_GUARDED, PS_NORM, PS_ABS = 0, 1, 2
+
+
+def power_spectrum(bins, nbin=None, mode=PS_NORM_GUARDED, scale=1.0, out=None):
+    """bins: [batch, nspec] complex64 CUDA tensor; uses the first nbin bins of each frame."""
+    import torch
+    assert bins.is_cuda and bins.dtype == torch.complex64 and bins.dim() == 2 and bins.is_contiguous()
+    batch, nspec = bins.shape
+    if nbin is None:
+        nbin = nspec
+    if out is None:
+        out = torch.empty((batch, nbin), dtype=torch.float32, device=bins.device)
+    _check(lib().dspmi_power_spectrum_f32(out.data_ptr(), bins.data_ptr(), nbin, nspec, batch, mode, scale, _stream()),
+           "power_spectrum")
+    return out
+
+
+class ToneGen:
+    """Per-channel tone generators with device-resident running phases (tonegen/tonegen.c)."""
+
+    def __init__(self, fsampl, freqs, amps=None, phis=None, use_sin=False, device="cuda"):
+        import torch
+        freqs = np.atleast_2d(np.asarray(freqs, dtype=np.float64))
+        self.nchan, self.ntone = freqs.shape
+        self.use_sin = use_sin
+        dw = (2.0 * np.pi * freqs) / fsampl          # tonegen/tonegen.c:22
+        amps = np.ones_like(freqs) if amps is None else np.array(np.broadcast_to(np.asarray(amps, np.float64), freqs.shape))
+        phis = np.zeros_like(freqs) if phis is None else np.array(np.broadcast_to(np.asarray(phis, np.float64), freqs.shape))
+        self.dw = torch.from_numpy(np.ascontiguousarray(dw)).to(device)
+        self.amp = torch.from_numpy(np.ascontiguousarray(amps)).to(device)
+        self.phi = torch.from_numpy(np.ascontiguousarray(phis)).to(device)
+        self.w = torch.zeros_like(self.dw)
+
+    def read(self, n, out=None):
+        import torch
+        if out is None:
+            out = torch.empty((self.nchan, n), dtype=torch.float32, device=self.w.device)
+        assert out.shape == (self.nchan, n) and out.stride(1) == 1
+        _check(lib().dspmi_tonegen_f32(out.data_ptr(), out.stride(0) if self.nchan > 1 else n, n, self.nchan, self.ntone,
+                                       self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
+                                       int(self.use_sin), _stream()), "tonegen")
+        return out
 
 
 class OlsPlan:

@@ -163,6 +163,28 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
                        unsigned nx, unsigned nchan, const float *hist, size_t hist_stride, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Stages either side of the FIR / FFT in the reference's chain              */
+/* ------------------------------------------------------------------------ */
+
+#define DSPMI_PS_NORM_GUARDED 0 /* |X|/sum if sum > 1e-5 else |X|: fft/src/main.c:120-141, util/fft/fft.c:73-94 */
+#define DSPMI_PS_NORM         1 /* |X|/sum, no guard: alsa/main.c:473-487 */
+#define DSPMI_PS_ABS          2 /* 2|X|/scale: fftc/main.c:80-105, fir/src/main.c:246-251 */
+
+/* ps[f][k] for k < nbin from bins[f][k] (dspmi_c32, in_stride complex elements between
+ * frames, so the first nbin bins of a longer spectrum can be used in place). */
+int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigned in_stride,
+                             size_t batch, int mode, float scale, void *stream);
+
+/* Tone generator of tonegen/tonegen.c:25-40 on the device, one generator per channel:
+ * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
+ * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from
+ * call to call.  use_sin != 0 selects the unit-amplitude sine form of fft/src/main.c:281-290
+ * (amp and phi unused).  ntone <= 8. */
+int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
+                      double *w, const double *dw, const double *amp, const double *phi,
+                      int use_sin, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Host drop-in wrappers (reference signatures; host double buffers)         */
 /* ------------------------------------------------------------------------ */
 

@@ -1,0 +1,92 @@
+"""Stages around the FIR / FFT (spectrum post-ops, tone generator) and the whole chain
+tone generator -> FIR low-pass -> N=4096 real FFT -> normalised magnitude spectrum, streamed in
+chunks with carried history, against the oracle run end to end on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+import dsp_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(got, want):
+    den = np.linalg.norm(want)
+    return np.linalg.norm(np.asarray(got, np.float64) - want) / den if den > 0 else np.linalg.norm(got)
+
+
+@pytest.mark.parametrize("nbin", [1, 63, 240, 1024, 2049, 5000])
+def test_power_spectrum_modes(nbin):
+    rng = np.random.default_rng(nbin)
+    z = (rng.standard_normal((6, nbin + 3)) + 1j * rng.standard_normal((6, nbin + 3))).astype(np.complex64)
+    z[1] *= 1e-9          # sum below the 1e-5 guard: left un-normalised by fft_to_power_spectrum
+    zd = torch.from_numpy(z).cuda()
+    got0 = dsp_amd.power_spectrum(zd, nbin, dsp_amd.PS_NORM_GUARDED).cpu().numpy()
+    got1 = dsp_amd.power_spectrum(zd, nbin, dsp_amd.PS_NORM).cpu().numpy()
+    got2 = dsp_amd.power_spectrum(zd, nbin, dsp_amd.PS_ABS, scale=float(2 * nbin)).cpu().numpy()
+    for f in range(6):
+        zz = z[f, :nbin].astype(np.complex128)
+        assert rel_l2(got0[f], oracle.power_spectrum(zz)) <= 2e-6
+        mag = np.abs(zz)
+        assert rel_l2(got1[f], mag / mag.sum()) <= 2e-6
+        zfull = np.concatenate([zz, np.zeros(nbin)])          # ps_abs looks at nx/2 bins of an nx-point spectrum
+        assert rel_l2(got2[f], oracle.ps_abs(zfull)) <= 2e-6
+    if nbin > 1:
+        assert abs(got1[0].sum() - 1.0) < 1e-5
+
+
+def test_tonegen_matches_recurrence_and_continues():
+    fs = 48000.0
+    freqs = np.array([[100.0 * (c + 1), 12000.0] for c in range(70)])
+    amps = np.array([[1.0, 0.5]] * 70)
+    phis = np.array([[0.0, 0.3]] * 70)
+    gen = dsp_amd.ToneGen(fs, freqs, amps, phis)
+    a = gen.read(1000).cpu().numpy()
+    b = gen.read(333).cpu().numpy()          # continues from the accumulated phases
+    for c in (0, 1, 37, 69):
+        t = oracle.Tonegen()
+        for j in range(2):
+            t.add(fs, freqs[c, j], amps[c, j], phis[c, j])
+        want = t.read(1333)
+        got = np.concatenate([a[c], b[c]])
+        assert np.abs(got - want.astype(np.float32)).max() <= 2e-7 * 1.5   # f32 rounding of a double sum
+    # the sine form of fft/src/main.c:265-291
+    g2 = dsp_amd.ToneGen(fs, [[100.0, 12000.0]], use_sin=True)
+    got = g2.read(4096).cpu().numpy()[0]
+    want = oracle.sin_tonegen([100.0, 12000.0], fs, 4096)
+    assert np.abs(got - want.astype(np.float32)).max() <= 3e-7
+
+
+def test_chain_streaming_matches_oracle_end_to_end():
+    """tonegen -> 16-tap FIR (alsa/main.c:389-407) -> N=4096 r2c -> |X|/sum, 3 chunks of 2 frames."""
+    fs, nchan, nfft, frames_per_chunk, nchunks = 48000.0, 5, 4096, 2, 3
+    freqs = np.array([[100.0 * (c + 1), 12000.0] for c in range(nchan)])
+    taps = oracle.TAPS16.astype(np.float32)
+    gen = dsp_amd.ToneGen(fs, freqs, use_sin=True)
+    fir = dsp_amd.FirPlan(taps, "f32")
+    fft = dsp_amd.FftPlan(nfft, "f32")
+    hist = torch.zeros((nchan, len(taps) - 1), dtype=torch.float32, device="cuda")
+    spectra, filtered = [], []
+    n = nfft * frames_per_chunk
+    for _ in range(nchunks):
+        x = gen.read(n)
+        y = fir.exec(x, n, hist=hist)
+        hist = x[:, -(len(taps) - 1):].contiguous()
+        bins = fft.r2c(y.view(nchan * frames_per_chunk, nfft))
+        spectra.append(dsp_amd.power_spectrum(bins).view(nchan, frames_per_chunk, nfft // 2 + 1).cpu().numpy())
+        filtered.append(y.cpu().numpy())
+    got_ps = np.concatenate(spectra, axis=1)
+    got_y = np.concatenate(filtered, axis=1)
+    total = n * nchunks
+    for c in range(nchan):
+        tone = oracle.sin_tonegen(list(freqs[c]), fs, total).astype(np.float32)
+        want_y = oracle.fir_batch_f32(tone, taps, total)[0]
+        assert rel_l2(got_y[c], want_y) <= 1e-6
+        for f in range(frames_per_chunk * nchunks):
+            want = oracle.power_spectrum(oracle.fft_r2c(want_y[f * nfft:(f + 1) * nfft]))
+            assert rel_l2(got_ps[c, f], want) <= 1e-5, (c, f)
+    # the 12 kHz tone is in the stop band of the 16-tap table (ripple ~0.35): its bin ends up
+    # below the pass-band tone's although both tones enter with unit amplitude
+    k_lo, k_hi = round(100.0 / fs * nfft), round(12000.0 / fs * nfft)
+    assert got_ps[0, 1, k_hi] < 0.5 * got_ps[0, 1, k_lo]

@@ -176,3 +176,21 @@ def test_linearity_and_impulse_at_scale():
     got = ya[:2, :20000].cpu().numpy()
     for c in range(2):
         assert rel_l2(got[c], want[c]) <= TOL_FIR
+
+
+@pytest.mark.parametrize("nh", [300, 127])
+def test_many_tiles_per_workgroup_walk(nh):
+    """Enough tiles that every workgroup walks several of them (the prefetch pipeline's steady
+    state), with a tap count between the two staging-register variants; spot rows vs the oracle."""
+    nchan, nx = 64, 1 << 21
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    g = torch.Generator(device="cuda").manual_seed(nh)
+    x = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
+    y = plan.exec(x)
+    for c in (0, 31, 63):
+        for lo in (0, nx // 2 - 5000, nx - 10000):
+            seg = x[c, max(0, lo - nh):lo + 10000].cpu().numpy()
+            want = oracle.fir_batch_f32(seg, h, len(seg))[0][lo - max(0, lo - nh):]
+            got = y[c, lo:lo + 10000].cpu().numpy()
+            assert rel_l2(got, want) <= TOL_FIR, (c, lo)
