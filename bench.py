@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir16", "fir8191", "ols8191"])
+    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir16", "fir8191", "ols8191", "chain"])
     ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
@@ -166,6 +166,45 @@ def make_long(args, rank, use_ols):
     return fn, info, (plan, x, y)
 
 
+def make_chain(args, rank):
+    """BASELINE config 5: per-channel tones -> FIR low-pass -> N=4096 real FFT -> normalised
+    magnitude spectrum, streamed in 4 chunks with the FIR history carried between chunks.
+    The tone input of every chunk is generated on the device beforehand (the generator's phase
+    recurrence is sequential in time; it is timed separately, see "tonegen_ms")."""
+    nchan, nfft, nchunk = 1024, 4096, 4
+    chunk = (1 << 20) // nchunk
+    nh = 127
+    taps = sinc_taps(nh)
+    freqs = np.array([[100.0 * (c + 1 + 1024 * rank), 12000.0] for c in range(nchan)])
+    gen = dsp_amd.ToneGen(48000.0, freqs, use_sin=True)
+    t0 = time.perf_counter()
+    xs = [gen.read(chunk) for _ in range(nchunk)]
+    torch.cuda.synchronize()
+    tonegen_ms = (time.perf_counter() - t0) * 1e3
+    fir = dsp_amd.FirPlan(taps, "f32")
+    fft = dsp_amd.FftPlan(nfft, "f32")
+    y = torch.empty((nchan, chunk), dtype=torch.float32, device="cuda")
+    bins = torch.empty((nchan * chunk // nfft, nfft // 2 + 1), dtype=torch.complex64, device="cuda")
+    ps = torch.empty((nchan * chunk // nfft, nfft // 2 + 1), dtype=torch.float32, device="cuda")
+    zero_hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
+
+    def step():
+        hist = zero_hist
+        for k in range(nchunk):
+            fir.exec(xs[k], chunk, y=y, hist=hist)
+            hist = xs[k][:, chunk - (nh - 1):]
+            fft.r2c(y.view(-1, nfft), out=bins)
+            dsp_amd.power_spectrum(bins, out=ps)
+
+    units = nchan * chunk * nchunk
+    info = dict(kernel="%s + r2c(%s) + power_spectrum" % (fir.variant, fft.variant), units=units, unit_name="samples",
+                nh=nh, flop_per_unit=2.0 * nh + 2.5 * math.log2(nfft), bytes_per_unit=4.0 + 2.0, bound="hbm",
+                samples_per_unit=1, tonegen_ms=tonegen_ms,
+                workload="chain: tones -> %d-tap FIR -> N=%d r2c -> |X|/sum, %d channels x %d samples in %d chunks"
+                         % (nh, nfft, nchan, chunk * nchunk, nchunk))
+    return step, info, (gen, xs, fir, fft, y, bins, ps)
+
+
 def measured_traffic(info):
     """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes
     (profiles/r1_traffic.json), or None when the workload was not profiled at this size."""
@@ -261,6 +300,9 @@ def main():
 
     if args.workload == "fft1024":
         fn, info, keep = make_fft(args, rank)
+    elif args.workload == "chain":
+        fn, info, keep = make_chain(args, rank)
+        args.no_secondary = True
     elif args.workload in ("fir8191", "ols8191"):
         fn, info, keep = make_long(args, rank, args.workload == "ols8191")
         args.no_secondary = True
@@ -294,9 +336,14 @@ def main():
 
     if rank == 0:
         is_fft = args.workload == "fft1024"
+        if is_fft:
+            metric = "FFT GFLOP/s (N=1024, c2c f32, 5*N*log2(N) flop per frame)"
+        elif args.workload == "chain":
+            metric = "Gsamples/s through the tonegen -> FIR -> FFT(4096) -> spectrum chain (f32)"
+        else:
+            metric = "Gsamples/s batched FIR (%d taps, f32)" % info["nh"]
         line = {
-            "metric": "FFT GFLOP/s (N=1024, c2c f32, 5*N*log2(N) flop per frame)" if is_fft
-                      else "Gsamples/s batched FIR (%d taps, f32)" % info["nh"],
+            "metric": metric,
             "value": round(gflops if is_fft else gsamples, 2),
             "unit": "GFLOP/s" if is_fft else "Gsamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -310,6 +357,8 @@ def main():
             "cpu_baseline": cpu,
             "secondary": secondary,
         }
+        if "tonegen_ms" in info:
+            line["tonegen_ms_untimed_setup"] = round(info["tonegen_ms"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -28,6 +28,7 @@ SOURCES = {
     "ols.hip": [],
     "spectrum.hip": [],
     "wrappers.cpp": ["-x", "hip"],
+    "fftw_shim.cpp": ["-x", "hip"],
 }
 
 

@@ -48,3 +48,20 @@ def test_no_oracle_or_cpu_path_in_the_product():
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "liboracle" not in txt and "dsp_oracle" not in txt, f
+
+
+def test_fftw_subset_symbols_exported():
+    lib = dsp_amd.lib()
+    names = [n for n in _declared("dspmi_fftw3.h") if n.startswith("dspmi_fftw_")]
+    assert sorted(names) == sorted(["dspmi_fftw_malloc", "dspmi_fftw_free", "dspmi_fftw_plan_dft_1d",
+                                    "dspmi_fftw_plan_dft_r2c_1d", "dspmi_fftw_plan_dft_c2r_1d",
+                                    "dspmi_fftw_execute", "dspmi_fftw_destroy_plan"])
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    # host-only entry points work without a device
+    lib.dspmi_fftw_malloc.restype = ctypes.c_void_p
+    lib.dspmi_fftw_malloc.argtypes = [ctypes.c_size_t]
+    lib.dspmi_fftw_free.argtypes = [ctypes.c_void_p]
+    p = lib.dspmi_fftw_malloc(1024)
+    assert p and p % 64 == 0
+    lib.dspmi_fftw_free(p)

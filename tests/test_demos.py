@@ -20,7 +20,7 @@ def _build():
 
 def test_demos_compile_as_plain_c():
     _build()
-    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo"):
+    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo"):
         assert os.path.exists(os.path.join(BIN, name))
 
 
@@ -73,3 +73,25 @@ def test_fftc_demo_matches_oracle(golden_dir):
     np.testing.assert_allclose(rows[:, 1], oracle.ps_abs(y), atol=2e-6)
     np.testing.assert_allclose(rows[:, 2], y.real[:240] / 240, atol=2e-6)
     np.testing.assert_allclose(rows[:, 3], -y.imag[:240] / 240, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_fftw_subset_demo_matches_oracle():
+    """The reference's wrappers compiled against include/dspmi_fftw3.h instead of <fftw3.h>."""
+    out = _run("fftw_demo").splitlines()
+    spec = np.array([[float(v) for v in ln.split()] for ln in out[:480]])
+    filt = np.array([[float(v) for v in ln.split()] for ln in out[480:]])
+    t = oracle.Tonegen()
+    t.add(48000, 2000, 100, 0); t.add(48000, 4000, 100, 0.666); t.add(48000, 6000, 100, 0)
+    x = t.read_complex(480)
+    y = oracle.dft(x, -1, "direct")
+    np.testing.assert_allclose(spec[:, 1], x.real, atol=1e-6)
+    np.testing.assert_allclose(spec[:, 2], x.real, atol=1e-6)          # backward(forward(x))/nx
+    np.testing.assert_allclose(spec[:, 3], y.real, atol=2e-6 * np.abs(y).max())
+    np.testing.assert_allclose(spec[:, 4], y.imag, atol=2e-6 * np.abs(y).max())
+    t = oracle.Tonegen()
+    t.add(48000, 1000, 1.0, 0); t.add(48000, 12000, 0.5, 0.3)
+    s = t.read(4096)
+    g = np.where(np.arange(2049) * 48000.0 / 4096 < 3000, 1.0, 0.0)
+    assert filt.shape == (4096, 3)
+    np.testing.assert_allclose(filt[:, 2], oracle.filter(s, g), atol=1e-6)
