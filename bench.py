@@ -184,7 +184,6 @@ def make_chain(args, rank):
     fir = dsp_amd.FirPlan(taps, "f32")
     fft = dsp_amd.FftPlan(nfft, "f32")
     y = torch.empty((nchan, chunk), dtype=torch.float32, device="cuda")
-    bins = torch.empty((nchan * chunk // nfft, nfft // 2 + 1), dtype=torch.complex64, device="cuda")
     ps = torch.empty((nchan * chunk // nfft, nfft // 2 + 1), dtype=torch.float32, device="cuda")
     zero_hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
 
@@ -193,16 +192,15 @@ def make_chain(args, rank):
         for k in range(nchunk):
             fir.exec(xs[k], chunk, y=y, hist=hist)
             hist = xs[k][:, chunk - (nh - 1):]
-            fft.r2c(y.view(-1, nfft), out=bins)
-            dsp_amd.power_spectrum(bins, out=ps)
+            fft.r2c_spectrum(y.view(-1, nfft), out=ps)   # r2c + |X| + normalise in one pass
 
     units = nchan * chunk * nchunk
-    info = dict(kernel="%s + r2c(%s) + power_spectrum" % (fir.variant, fft.variant), units=units, unit_name="samples",
+    info = dict(kernel="%s + r2c_spectrum(%s)" % (fir.variant, fft.variant), units=units, unit_name="samples",
                 nh=nh, flop_per_unit=2.0 * nh + 2.5 * math.log2(nfft), bytes_per_unit=4.0 + 2.0, bound="hbm",
                 samples_per_unit=1, tonegen_ms=tonegen_ms,
                 workload="chain: tones -> %d-tap FIR -> N=%d r2c -> |X|/sum, %d channels x %d samples in %d chunks"
                          % (nh, nfft, nchan, chunk * nchunk, nchunk))
-    return step, info, (gen, xs, fir, fft, y, bins, ps)
+    return step, info, (gen, xs, fir, fft, y, ps)
 
 
 def measured_traffic(info):

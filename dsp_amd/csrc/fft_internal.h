@@ -13,11 +13,18 @@ namespace dspmi {
 typedef int (*fft_launch_fn)(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu,
                              hipStream_t s);
 
+// Real input through this N-point complex kernel: in = batch frames of 2N reals; epilogue 1
+// writes bins 0..N (N+1 complex per frame), epilogue 2 writes the magnitude spectrum over nbin
+// (N or N+1) bins normalised per `mode` (DSPMI_PS_*).  tw2n = exp(-2 pi i k / 2N), k < N.
+typedef int (*fft_r2c_launch_fn)(const void *in, void *out, const void *tw, const void *tw2n, size_t batch, int epilogue,
+                                 unsigned nbin, int mode, float scale, int num_cu, hipStream_t s);
+
 struct FftKernel {
     unsigned n;
     fft_launch_fn fn;         // default cache policy
     fft_launch_fn fn_stream;  // nontemporal loads and stores: batches far larger than the caches
     const char *name;
+    fft_r2c_launch_fn fn_r2c;  // fused real-input form, or nullptr
 };
 
 // Kernel for a power-of-two length, or nullptr.

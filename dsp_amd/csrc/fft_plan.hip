@@ -274,8 +274,8 @@ struct dspmi_fft_plan {
     const dspmi::FftKernel *kern_M = nullptr;
     void *tw_M = nullptr, *chirp = nullptr, *filt = nullptr;
     // scratch, grown on demand (allocation happens in exec only when a batch outgrows it)
-    void *work[2] = {nullptr, nullptr};
-    size_t work_bytes[2] = {0, 0};
+    void *work[3] = {nullptr, nullptr, nullptr};  // 0: Bluestein, 1: real transforms, 2: spectrum bins
+    size_t work_bytes[3] = {0, 0, 0};
     char name[64] = "";
 };
 
@@ -360,6 +360,8 @@ int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
+    if (pl->kern_half && pl->kern_half->fn_r2c)  // fused: transform + split in one kernel
+        return pl->kern_half->fn_r2c(in, out, pl->tw_half, pl->tw_n, batch, 1, n / 2 + 1, 0, 0.f, pl->num_cu, s);
     if (pl->kern_half) {
         int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
         if (rc != DSPMI_OK) return rc;
@@ -484,7 +486,7 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
 int dspmi_fft_destroy(dspmi_fft_t plan)
 {
     if (!plan) return DSPMI_OK;
-    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1]};
+    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1], plan->work[2]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete plan;
@@ -523,6 +525,27 @@ int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch
     if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     return plan->precision == DSPMI_F64 ? c2r_typed<double>(plan, in, out, batch, s) : c2r_typed<float>(plan, in, out, batch, s);
+}
+
+int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, size_t batch, unsigned nbin, int mode,
+                                float scale, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: null plan");
+    if (plan->precision != DSPMI_F32) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_r2c_spectrum: f32 plans only");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !ps) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: null buffer");
+    if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: mode must be 0, 1 or 2");
+    const unsigned n = plan->n;
+    if (nbin == 0 || nbin > n / 2 + 1) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: nbin must be 1..n/2+1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->kern_half && plan->kern_half->fn_r2c && nbin >= n / 2)
+        return plan->kern_half->fn_r2c(in, ps, plan->tw_half, plan->tw_n, batch, 2, nbin, mode, scale, plan->num_cu, s);
+    // any other length: bins to scratch, then the stand-alone spectrum kernel
+    int rc = ensure_work(plan, 2, batch * (size_t)(n / 2 + 1) * sizeof(C<float>));
+    if (rc != DSPMI_OK) return rc;
+    rc = r2c_typed<float>(plan, in, plan->work[2], batch, s);
+    if (rc != DSPMI_OK) return rc;
+    return dspmi_power_spectrum_f32(ps, plan->work[2], nbin, n / 2 + 1, batch, mode, scale, stream);
 }
 
 const char *dspmi_fft_variant(dspmi_fft_t plan)

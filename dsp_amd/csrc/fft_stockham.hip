@@ -209,6 +209,49 @@ __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, co
     }
 }
 
+// Per-workgroup twiddle tables behind the FPB frame buffers: pass p holds W^{k*r},
+// r = 1..R-1, k < NS, as [r-1][k] so a wave reads contiguous entries.  Ends with a barrier.
+template <typename T, int N, int BT, int FPB, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ void setup_lds_twiddles(char *smem_raw, const C<T> *__restrict__ tw, const C<T> *&tw1,
+                                                   const C<T> *&tw2, const C<T> *&tw3)
+{
+    constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
+    C<T> *t1 = reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N);
+    C<T> *t2 = t1 + (R1 > 1 ? (R1 - 1) * NS1 : 0);
+    C<T> *t3 = t2 + (R2 > 1 ? (R2 - 1) * NS2 : 0);
+    if constexpr (R1 > 1)
+        for (unsigned i = threadIdx.x; i < (R1 - 1) * NS1; i += BT) t1[i] = tw[(i % NS1) * (i / NS1 + 1) * (N / (NS1 * R1))];
+    if constexpr (R2 > 1)
+        for (unsigned i = threadIdx.x; i < (R2 - 1) * NS2; i += BT) t2[i] = tw[(i % NS2) * (i / NS2 + 1) * (N / (NS2 * R2))];
+    if constexpr (R3 > 1)
+        for (unsigned i = threadIdx.x; i < (R3 - 1) * NS3; i += BT) t3[i] = tw[(i % NS3) * (i / NS3 + 1) * (N / (NS3 * R3))];
+    __syncthreads();
+    tw1 = t1;
+    tw2 = t2;
+    tw3 = t3;
+}
+
+constexpr size_t lds_twiddle_entries(int TW, int R0, int R1, int R2, int R3)
+{
+    return TW == 2 ? (size_t)(R1 > 1 ? (R1 - 1) * R0 : 0) + (R2 > 1 ? (R2 - 1) * R0 * R1 : 0) +
+                         (R3 > 1 ? (R3 - 1) * R0 * R1 * R2 : 0)
+                   : 0;
+}
+
+// All passes of one frame: v holds the first pass's inputs on entry and the last pass's
+// outputs (butterfly j = tl + NT*b, output r at position j + r*N/RLAST) on return.
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW>
+__device__ __forceinline__ void run_passes(C<T> *v, C<T> *lds, const C<T> *tw1, const C<T> *tw2, const C<T> *tw3,
+                                           const C<T> *__restrict__ tw, unsigned tl)
+{
+    constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    fft_pass<T, N, NT, R0, 1, true, NPASS == 1, TW>(v, lds, nullptr, tw, tl);
+    if constexpr (R1 > 1) fft_pass<T, N, NT, R1, NS1, false, NPASS == 2, TW>(v, lds, tw1, tw, tl);
+    if constexpr (R2 > 1) fft_pass<T, N, NT, R2, NS2, false, NPASS == 3, TW>(v, lds, tw2, tw, tl);
+    if constexpr (R3 > 1) fft_pass<T, N, NT, R3, NS3, false, NPASS == 4, TW>(v, lds, tw3, tw, tl);
+}
+
 template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
 
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
@@ -240,21 +283,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
         load_twiddles<T, N, NT, R2, NS2>(tw2r, tw, tl);
         load_twiddles<T, N, NT, R3, NS3>(tw3r, tw, tl);
     }
-    if constexpr (TW == 2) {
-        // per-workgroup twiddle tables behind the frame buffers: pass p holds
-        // W^{k*r}, r = 1..R-1, k < NS, as [r-1][k] so a wave reads contiguous entries
-        C<T> *t1 = reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N);
-        C<T> *t2 = t1 + (R1 > 1 ? (R1 - 1) * NS1 : 0);
-        C<T> *t3 = t2 + (R2 > 1 ? (R2 - 1) * NS2 : 0);
-        if constexpr (R1 > 1)
-            for (unsigned i = threadIdx.x; i < (R1 - 1) * NS1; i += BT) t1[i] = tw[(i % NS1) * (i / NS1 + 1) * (N / (NS1 * R1))];
-        if constexpr (R2 > 1)
-            for (unsigned i = threadIdx.x; i < (R2 - 1) * NS2; i += BT) t2[i] = tw[(i % NS2) * (i / NS2 + 1) * (N / (NS2 * R2))];
-        if constexpr (R3 > 1)
-            for (unsigned i = threadIdx.x; i < (R3 - 1) * NS3; i += BT) t3[i] = tw[(i % NS3) * (i / NS3 + 1) * (N / (NS3 * R3))];
-        __syncthreads();
-        tw1 = t1; tw2 = t2; tw3 = t3;
-    }
+    if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
     const T sgn = backward ? T(-1) : T(1);
 
     const size_t nfb = (batch + FPB - 1) / FPB;
@@ -279,10 +308,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
         C<T> *dst = out + frame * N;
 #pragma unroll
         for (int i = 0; i < P; i++) v[i].im *= sgn;
-        fft_pass<T, N, NT, R0, 1, true, NPASS == 1, TW>(v, lds, nullptr, tw, tl);
-        if constexpr (R1 > 1) fft_pass<T, N, NT, R1, NS1, false, NPASS == 2, TW>(v, lds, tw1, tw, tl);
-        if constexpr (R2 > 1) fft_pass<T, N, NT, R2, NS2, false, NPASS == 3, TW>(v, lds, tw2, tw, tl);
-        if constexpr (R3 > 1) fft_pass<T, N, NT, R3, NS3, false, NPASS == 4, TW>(v, lds, tw3, tw, tl);
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
         // last pass writes global memory: butterfly j, output r goes to j + r*N/RLAST
         if (active) {
 #pragma unroll
@@ -326,6 +352,136 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
 }
 
 // ---------------------------------------------------------------------------
+// real input: n = 2N real samples per frame through one N-point complex transform
+// ---------------------------------------------------------------------------
+
+// Sum of `val` over the NT lanes that own one frame.
+template <int NT>
+__device__ __forceinline__ float frame_sum(float val, float *scratch, unsigned slot, unsigned tl)
+{
+    constexpr int W = NT < 64 ? NT : 64;
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) val += __shfl_xor(val, off, 64);
+    if constexpr (NT > 64) {
+        constexpr int NW = NT / 64;
+        __syncthreads();
+        if ((tl & 63) == 0) scratch[slot * NW + tl / 64] = val;
+        __syncthreads();
+        val = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) val += scratch[slot * NW + w];
+    }
+    return val;
+}
+
+// EPI 1: out = bins 0..N of the 2N-point real transform (the fftw_plan_dft_r2c_1d contract,
+//        fft/src/main.c:155-158), N+1 complex per frame.
+// EPI 2: out = magnitude spectrum over nbin bins (N+1 or N), normalised as `mode` says
+//        (0: divide by the sum when it exceeds 1e-5, fft/src/main.c:120-141;
+//         1: always divide, alsa/main.c:473-487; 2: 2|X|/scale, fftc/main.c:80-105).
+// The frame's packed transform Z stays on chip: it is parked in the frame's LDS image and
+// bin k is formed from Z[k] and Z[N-k] there (X[k] = E[k] + W_2N^k O[k]).
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, int EPI>
+__global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T> *in, void *out_raw,
+                                                                      const C<T> *__restrict__ tw,
+                                                                      const C<T> *__restrict__ tw2n, size_t batch,
+                                                                      unsigned nbin, int mode, float scale)
+{
+    static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
+    constexpr int P = N / NT;
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
+    constexpr int NSLAST = N / RLAST;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned slot = threadIdx.x / NT;
+    const unsigned tl = threadIdx.x % NT;
+    C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
+    float *scratch = reinterpret_cast<float *>(reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N) +
+                                               lds_twiddle_entries(TW, R0, R1, R2, R3));
+
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const size_t frame = fb * FPB + slot;
+        const bool active = frame < batch;
+        const C<T> *src = in + frame * N;  // 2N reals read as N complex points
+        C<T> v[P];
+#pragma unroll
+        for (int b = 0; b < P / R0; b++)
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                C<T> q = {T(0), T(0)};
+                if (active) q = nt_load(&src[tl + NT * b + r * (N / R0)]);
+                v[b * R0 + r] = q;
+            }
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+
+        // park Z in natural order (the last pass's LDS reads are behind a frame_sync already)
+#pragma unroll
+        for (int b = 0; b < P / RLAST; b++)
+#pragma unroll
+            for (int r = 0; r < RLAST; r++) lds[pad(tl + NT * b + r * NSLAST)] = v[b * RLAST + r];
+        frame_sync<NT>();
+
+        // bins k = tl + NT*i, i < P; the lane with k = 0 also forms bin N (Nyquist)
+        C<T> x[P];
+        C<T> nyq = {T(0), T(0)};
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const unsigned k = tl + NT * i;
+            const C<T> a = lds[pad(k)];
+            const C<T> b0 = lds[pad((N - k) & (N - 1))];
+            const C<T> e = {(a.re + b0.re) * T(0.5), (a.im - b0.im) * T(0.5)};
+            const C<T> d = {(a.re - b0.re) * T(0.5), (a.im + b0.im) * T(0.5)};
+            const C<T> o = {d.im, -d.re};  // -i * d
+            const C<T> w = tw2n[k];        // exp(-2 pi i k / 2N)
+            const C<T> wo = cmul(w, o);
+            x[i] = {e.re + wo.re, e.im + wo.im};
+            if (k == 0) nyq = {a.re - a.im, T(0)};
+        }
+        frame_sync<NT>();  // reads done before the next frame's passes overwrite the image
+
+        if constexpr (EPI == 1) {
+            C<T> *dst = static_cast<C<T> *>(out_raw) + frame * (N + 1);
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < P; i++) nt_store(x[i], &dst[tl + NT * i]);
+                if (tl == 0) dst[N] = nyq;
+            }
+        } else {
+            float mag[P];
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                mag[i] = sqrtf((float)(x[i].re * x[i].re + x[i].im * x[i].im));
+                part += mag[i];
+            }
+            const float mnyq = fabsf((float)nyq.re);
+            if (tl == 0 && nbin > N) part += mnyq;
+            float div = 1.f, mul = 1.f;
+            if (mode == 2) {
+                mul = 2.f;
+                div = scale;
+            } else {
+                const float sum = frame_sum<NT>(part, scratch, slot, tl);
+                if (mode == 1 || sum > 0.00001f) div = sum;
+            }
+            float *dst = static_cast<float *>(out_raw) + frame * nbin;
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < P; i++) __builtin_nontemporal_store((mul * mag[i]) / div, &dst[tl + NT * i]);
+                if (tl == 0 && nbin > N) dst[N] = (mul * mnyq) / div;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers and the kernel table
 // ---------------------------------------------------------------------------
 
@@ -335,9 +491,7 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     constexpr int BT = block_threads<NT>();
     constexpr int FPB = BT / NT;
     constexpr bool single_pass = R1 == 1 && R2 == 1 && R3 == 1;  // global -> registers -> global
-    constexpr size_t tw_entries = TW == 2 ? (R1 > 1 ? (R1 - 1) * R0 : 0) + (R2 > 1 ? (R2 - 1) * R0 * R1 : 0) +
-                                                (R3 > 1 ? (R3 - 1) * R0 * R1 * R2 : 0)
-                                          : 0;
+    constexpr size_t tw_entries = lds_twiddle_entries(TW, R0, R1, R2, R3);
     constexpr size_t lds = single_pass ? 0 : ((size_t)FPB * padded_len(N) + tw_entries) * sizeof(C<T>);
     auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TW, PREFETCH, NTMEM>;
     static bool attr_set = false;
@@ -372,16 +526,45 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     return DSPMI_OK;
 }
 
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW>
+int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size_t batch, int epilogue, unsigned nbin,
+               int mode, float scale, int num_cu, hipStream_t s)
+{
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<T>) +
+                           (size_t)FPB * (NT > 64 ? NT / 64 : 1) * sizeof(float);
+    auto k1 = fft_r2c_kernel<T, N, NT, R0, R1, R2, R3, TW, 1>;
+    auto k2 = fft_r2c_kernel<T, N, NT, R0, R1, R2, R3, TW, 2>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (batch == 0) return DSPMI_OK;
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    size_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 2048 / BT) per_cu = 2048 / BT;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = (size_t)num_cu * per_cu;
+    if (grid > nfb) grid = nfb;
+    hipLaunchKernelGGL(epilogue == 1 ? k1 : k2, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), out,
+                       static_cast<const C<T> *>(tw), static_cast<const C<T> *>(tw2n), batch, nbin, mode, scale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
 typedef dspmi::FftKernel FftEntry;
 
 // f32: twiddles in a per-workgroup LDS table (registers stay free for the butterflies: 4 waves
 // per SIMD instead of 2); f64: twiddles read from the global table through L1.
 #define F32(N, NT, A, B, C_, D)                                                                             \
     {N, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 3>, \
-     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D, launch_r2c<float, N, NT, A, B, C_, D, 2>}
 #define F64(N, NT, A, B, C_, D)                                                                               \
     {N, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, \
-     "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D}
+     "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr}
 
 const FftEntry kF32[] = {
     F32(2, 1, 2, 1, 1, 1),          F32(4, 1, 4, 1, 1, 1),          F32(8, 1, 8, 1, 1, 1),
@@ -391,7 +574,7 @@ const FftEntry kF32[] = {
     F32(8192, 512, 16, 16, 16, 2),
     // 16384 points fill the LDS with the frame alone: twiddles come from the global table
     {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 3>,
-     "fft_f32_n16384_r16x16x16x4"},
+     "fft_f32_n16384_r16x16x16x4", nullptr},
 };
 const FftEntry kF64[] = {
     F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),
@@ -403,9 +586,9 @@ const FftEntry kF64[] = {
 
 // alternative kernels for A/B runs: DSPMI_FFT_VARIANT=<index>
 const FftEntry kF32Alt1024[] = {
-    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, "fft_f32_n1024_r16x16x4_twreg"},
-    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true, 3>, "fft_f32_n1024_r16x16x4_twlds_pf"},
-    {1024, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false, 3>, "fft_f32_n1024_r16x8x8_twlds"},
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, "fft_f32_n1024_r16x16x4_twreg", nullptr},
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true, 3>, "fft_f32_n1024_r16x16x4_twlds_pf", nullptr},
+    {1024, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false, 3>, "fft_f32_n1024_r16x8x8_twlds", nullptr},
 };
 
 const FftEntry *find_entry(unsigned n, int precision)

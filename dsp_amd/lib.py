@@ -55,6 +55,7 @@ _SIGS = {
     "dspmi_ols_destroy": (C.c_int, [_vp]),
     "dspmi_ols_fft_length": (_u, [_vp]),
     "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
+    "dspmi_fft_exec_r2c_spectrum": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
     "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
@@ -194,6 +195,19 @@ class FftPlan:
         if out is None:
             out = torch.empty(x.shape[:-1] + (self.n // 2 + 1,), dtype=ct, device=x.device)
         _check(lib().dspmi_fft_exec_r2c(self._h, x.data_ptr(), out.data_ptr(), batch, _stream()), "fft_exec_r2c")
+        return out
+
+    def r2c_spectrum(self, x, nbin=None, mode=0, scale=1.0, out=None):
+        """Real frames -> normalised magnitude spectrum in one pass (f32 plans)."""
+        import torch
+        assert not self.f64 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == self.n
+        batch = x.numel() // self.n
+        if nbin is None:
+            nbin = self.n // 2 + 1
+        if out is None:
+            out = torch.empty(x.shape[:-1] + (nbin,), dtype=torch.float32, device=x.device)
+        _check(lib().dspmi_fft_exec_r2c_spectrum(self._h, x.data_ptr(), out.data_ptr(), batch, nbin, mode, scale, _stream()),
+               "fft_exec_r2c_spectrum")
         return out
 
     def c2r(self, x, out=None):

@@ -175,6 +175,12 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
 int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigned in_stride,
                              size_t batch, int mode, float scale, void *stream);
 
+/* Real frames straight to their magnitude spectrum (r2c + dspmi_power_spectrum_f32 in one
+ * pass over memory): in [batch][n] reals, ps [batch][nbin] with nbin = n/2+1 (fft/src) or n/2
+ * (alsa).  f32 plans; the fused kernel covers even n with a power-of-two half. */
+int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, size_t batch,
+                                unsigned nbin, int mode, float scale, void *stream);
+
 /* Tone generator of tonegen/tonegen.c:25-40 on the device, one generator per channel:
  * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from

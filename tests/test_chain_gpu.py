@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def rel_l2(got, want):
     den = np.linalg.norm(want)
-    return np.linalg.norm(np.asarray(got, np.float64) - want) / den if den > 0 else np.linalg.norm(got)
+    return np.linalg.norm(np.asarray(got) - want) / den if den > 0 else np.linalg.norm(got)
 
 
 @pytest.mark.parametrize("nbin", [1, 63, 240, 1024, 2049, 5000])
@@ -90,3 +90,23 @@ def test_chain_streaming_matches_oracle_end_to_end():
     # below the pass-band tone's although both tones enter with unit amplitude
     k_lo, k_hi = round(100.0 / fs * nfft), round(12000.0 / fs * nfft)
     assert got_ps[0, 1, k_hi] < 0.5 * got_ps[0, 1, k_lo]
+
+
+@pytest.mark.parametrize("n", [4, 8, 64, 1024, 4096, 8192, 16384, 1000])
+def test_fused_r2c_spectrum(n):
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, (9, n)).astype(np.float32)
+    x[3] *= 1e-10                                     # below the 1e-5 guard
+    plan = dsp_amd.FftPlan(n, "f32")
+    xd = torch.from_numpy(x).cuda()
+    ps0 = plan.r2c_spectrum(xd).cpu().numpy()
+    ps1 = plan.r2c_spectrum(xd, nbin=n // 2, mode=dsp_amd.PS_NORM).cpu().numpy()
+    ps2 = plan.r2c_spectrum(xd, nbin=n // 2, mode=dsp_amd.PS_ABS, scale=float(n)).cpu().numpy()
+    bins = plan.r2c(xd).cpu().numpy()
+    for f in range(9):
+        want_bins = oracle.fft_r2c(x[f].astype(np.float64))
+        assert rel_l2(bins[f], want_bins) <= 1e-5
+        assert rel_l2(ps0[f], oracle.power_spectrum(want_bins)) <= 1e-5
+        mag = np.abs(want_bins[:n // 2])
+        assert rel_l2(ps1[f], mag / mag.sum()) <= 1e-5
+        assert rel_l2(ps2[f], 2 * mag / n) <= 1e-5
