@@ -30,4 +30,16 @@ struct FftKernel {
 // Kernel for a power-of-two length, or nullptr.
 const FftKernel *fft_find(unsigned n, int precision);
 
+// Fused overlap-save (f32): blocks of N samples overlapping by nh-1, two real blocks per
+// complex transform, H = FFT_N(taps)/N (device, N complex).  All pointers are device pointers.
+struct OlsLaunch {
+    const float *x, *hist;
+    float *y;
+    const void *H;
+    size_t x_stride, y_stride, hist_stride;
+    unsigned nx, nh, nchan;
+};
+typedef int (*ols_launch_fn)(const OlsLaunch &o, const void *tw, int num_cu, hipStream_t s);
+ols_launch_fn ols_find(unsigned n);
+
 }  // namespace dspmi

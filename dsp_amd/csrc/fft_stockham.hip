@@ -482,6 +482,149 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
 }
 
 // ---------------------------------------------------------------------------
+// overlap-save: load two real blocks, transform, multiply by H, transform back, keep
+// the part that does not wrap -- one kernel, the block never leaves the CU
+// ---------------------------------------------------------------------------
+
+struct OlsArgs {
+    const float *x, *hist;
+    float *y;
+    const C<float> *H;  // FFT_N(taps) / N
+    size_t x_stride, y_stride, hist_stride;
+    unsigned nx, nh, L, nblk, npair, nchan;
+};
+
+// The radix list is symmetric (R0 == last radix), so the positions a lane holds after the
+// forward transform's last pass (j + r*N/R) are exactly the ones the backward transform's
+// first pass wants: the spectrum is multiplied in registers and goes straight back in.
+template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
+__global__ __launch_bounds__(block_threads<NT>()) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
+{
+    typedef float T;
+    static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
+    constexpr int P = N / NT;
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
+    static_assert(RLAST == R0, "first and last radix must match");
+    constexpr int STEP = N / R0;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned slot = threadIdx.x / NT;
+    const unsigned tl = threadIdx.x % NT;
+    C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+
+    const long nx = a.nx, nh = a.nh, L = a.L;
+    const size_t total = (size_t)a.nchan * a.npair;
+    const size_t nfb = (total + FPB - 1) / FPB;
+    for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const size_t frame = fb * FPB + slot;
+        const bool active = frame < total;
+        const size_t c = active ? frame / a.npair : 0;
+        const unsigned p = active ? (unsigned)(frame - c * a.npair) : 0;
+        const float *xrow = a.x + c * a.x_stride;
+        const float *hrow = a.hist ? a.hist + c * a.hist_stride : nullptr;
+        const long base = (long)(2 * p) * L - (nh - 1);  // sample index of element 0 of the even block
+        const bool second = 2 * p + 1 < a.nblk;
+        const bool interior = active && base >= 0 && base + L + N <= nx && second;
+
+        C<T> v[P];
+#pragma unroll
+        for (int b = 0; b < P / R0; b++)
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                const long s = base + tl + NT * b + r * STEP;
+                C<T> q = {0.f, 0.f};
+                if (interior) {
+                    q.re = __builtin_nontemporal_load(&xrow[s]);
+                    q.im = __builtin_nontemporal_load(&xrow[s + L]);
+                } else if (active) {
+                    if (s >= 0) q.re = s < nx ? xrow[s] : 0.f;
+                    else if (hrow && s >= 1 - nh) q.re = hrow[nh - 1 + s];
+                    const long s2 = s + L;
+                    if (second) {
+                        if (s2 >= 0) q.im = s2 < nx ? xrow[s2] : 0.f;
+                        else if (hrow && s2 >= 1 - nh) q.im = hrow[nh - 1 + s2];
+                    }
+                }
+                v[b * R0 + r] = q;
+            }
+
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+        // spectrum times H, conjugated for the backward transform (conj . forward . conj)
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const unsigned pos = tl + NT * (i / R0) + (i % R0) * STEP;
+            const C<T> hq = a.H[pos];
+            const C<T> m = cmul(v[i], hq);
+            v[i] = {m.re, -m.im};
+        }
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+
+        if (active) {
+            float *yrow = a.y + c * a.y_stride;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const long pos = tl + NT * (i / R0) + (i % R0) * STEP;
+                const long j = pos - (nh - 1);
+                if (j >= 0) {
+                    const long o0 = (long)(2 * p) * L + j;
+                    if (o0 < nx) __builtin_nontemporal_store(v[i].re, &yrow[o0]);
+                    if (second && o0 + L < nx) __builtin_nontemporal_store(-v[i].im, &yrow[o0 + L]);
+                }
+            }
+        }
+    }
+}
+
+template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
+int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_t s)
+{
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<float>);
+    auto kern = ols_fused_kernel<N, NT, R0, R1, R2, R3, TW>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    OlsArgs a;
+    a.x = o.x; a.hist = o.hist; a.y = o.y; a.H = static_cast<const C<float> *>(o.H);
+    a.x_stride = o.x_stride; a.y_stride = o.y_stride; a.hist_stride = o.hist_stride;
+    a.nx = o.nx; a.nh = o.nh; a.L = N - (o.nh - 1);
+    a.nblk = (o.nx + a.L - 1) / a.L;
+    a.npair = (a.nblk + 1) / 2;
+    a.nchan = o.nchan;
+    const size_t total = (size_t)a.nchan * a.npair;
+    if (total == 0) return DSPMI_OK;
+    const size_t nfb = (total + FPB - 1) / FPB;
+    size_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 2048 / BT) per_cu = 2048 / BT;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = (size_t)num_cu * per_cu;
+    if (grid > nfb) grid = nfb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, a, static_cast<const C<float> *>(tw));
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+struct OlsEntry {
+    unsigned n;
+    dspmi::ols_launch_fn fn;
+};
+#define OLS(N, NT, A, B, C_, D, TW) {N, launch_ols<N, NT, A, B, C_, D, TW>}
+const OlsEntry kOls[] = {
+    OLS(16, 1, 16, 1, 1, 1, 0),        OLS(32, 2, 4, 2, 4, 1, 2),          OLS(64, 4, 4, 4, 4, 1, 2),
+    OLS(128, 8, 4, 8, 4, 1, 2),        OLS(256, 16, 16, 16, 1, 1, 2),      OLS(512, 32, 16, 2, 16, 1, 2),
+    OLS(1024, 64, 16, 4, 16, 1, 2),    OLS(2048, 128, 16, 8, 16, 1, 2),    OLS(4096, 256, 16, 16, 16, 1, 2),
+    OLS(8192, 512, 16, 16, 2, 16, 2),  OLS(16384, 1024, 16, 16, 4, 16, 0),
+};
+
+// ---------------------------------------------------------------------------
 // launchers and the kernel table
 // ---------------------------------------------------------------------------
 
@@ -562,6 +705,11 @@ typedef dspmi::FftKernel FftEntry;
 #define F32(N, NT, A, B, C_, D)                                                                             \
     {N, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 3>, \
      "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D, launch_r2c<float, N, NT, A, B, C_, D, 2>}
+// same, with the next frame's global loads issued before the current frame is computed
+// (frames that span several waves keep few frames in flight per CU otherwise)
+#define F32P(N, NT, A, B, C_, D)                                                                          \
+    {N, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 3>, \
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D "_pf", launch_r2c<float, N, NT, A, B, C_, D, 2>}
 #define F64(N, NT, A, B, C_, D)                                                                               \
     {N, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, \
      "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr}
@@ -570,8 +718,8 @@ const FftEntry kF32[] = {
     F32(2, 1, 2, 1, 1, 1),          F32(4, 1, 4, 1, 1, 1),          F32(8, 1, 8, 1, 1, 1),
     F32(16, 1, 16, 1, 1, 1),        F32(32, 2, 16, 2, 1, 1),        F32(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
-    F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),   F32(4096, 256, 16, 16, 16, 1),
-    F32(8192, 512, 16, 16, 16, 2),
+    F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),   F32P(4096, 256, 16, 16, 16, 1),
+    F32P(8192, 512, 16, 16, 16, 2),
     // 16384 points fill the LDS with the frame alone: twiddles come from the global table
     {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 3>,
      "fft_f32_n16384_r16x16x16x4", nullptr},
@@ -609,5 +757,12 @@ const FftEntry *find_entry(unsigned n, int precision)
 namespace dspmi {
 
 const FftKernel *fft_find(unsigned n, int precision) { return find_entry(n, precision); }
+
+ols_launch_fn ols_find(unsigned n)
+{
+    for (const OlsEntry &e : kOls)
+        if (e.n == n) return e.fn;
+    return nullptr;
+}
 
 }  // namespace dspmi

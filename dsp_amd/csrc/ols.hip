@@ -10,8 +10,10 @@
 // blocks ride through one complex transform as re + i*im and come back separated, so no
 // real<->complex split pass is needed.  H = FFT_N(h)/N is computed once per plan.
 //
-// This file is the composition (gather blocks -> batched FFT -> multiply -> batched FFT
-// -> scatter valid part); the transforms are the kernels of fft_stockham.hip.
+// The measured path is the fused kernel of fft_stockham.hip (ols_fused_kernel: the block is
+// loaded, transformed, multiplied, transformed back and stored without leaving the CU); the
+// five-kernel composition below (gather -> batched FFT -> multiply -> batched FFT -> scatter)
+// is the same arithmetic through HBM, kept as the A/B reference (DSPMI_OLS_COMPOSED=1).
 #include "common.h"
 #include "fft_internal.h"
 
@@ -96,6 +98,7 @@ struct dspmi_ols_plan {
     int device = 0, num_cu = 256;
     unsigned nh = 0, N = 0, L = 0;
     const dspmi::FftKernel *kern = nullptr;
+    dspmi::ols_launch_fn fused = nullptr;  // one-kernel form (nullptr: composed path below)
     void *tw = nullptr;    // exp(-2 pi i k / N)
     void *H = nullptr;     // FFT_N(taps) / N
     void *work = nullptr;  // [nchan][npair][N] complex
@@ -127,6 +130,10 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     pl->N = N;
     pl->L = N - (nh - 1);
     pl->kern = dspmi::fft_find(N, DSPMI_F32);
+    {
+        const char *env = getenv("DSPMI_OLS_COMPOSED");  // A/B knob: force the five-kernel composition
+        if (!(env && atoi(env))) pl->fused = dspmi::ols_find(N);
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) pl->num_cu = prop.multiProcessorCount;
 
@@ -175,6 +182,13 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
     if (x_stride < nx || y_stride < nx) return dspmi::fail(DSPMI_EINVAL, "ols_exec: stride smaller than the row length");
     if (hist && hist_stride + 1 < plan->nh) return dspmi::fail(DSPMI_EINVAL, "ols_exec: hist_stride < nh-1");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->fused) {
+        dspmi::OlsLaunch o;
+        o.x = x; o.hist = hist; o.y = y; o.H = plan->H;
+        o.x_stride = x_stride; o.y_stride = y_stride; o.hist_stride = hist_stride;
+        o.nx = nx; o.nh = plan->nh; o.nchan = nchan;
+        return plan->fused(o, plan->tw, plan->num_cu, s);
+    }
     OlsShape sh;
     sh.N = plan->N; sh.L = plan->L; sh.nh = plan->nh;
     sh.nblk = (nx + sh.L - 1) / sh.L;
