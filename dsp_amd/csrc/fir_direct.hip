@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMfmaTile = 4096;  // outputs per workgroup: 4 waves x 4 tiles x 256
+constexpr int mfma_tile(int TPW) { return 4 * TPW * 256; }  // outputs per workgroup: 4 waves x TPW tiles x 256
 constexpr int kMfmaSeg = 2048;   // taps per LDS staging round
 
 // 16 consecutive floats, then two pads.  One 4-byte LDS read serves 32 lanes: the 16
@@ -195,12 +195,13 @@ constexpr int kMfmaSeg = 2048;   // taps per LDS staging round
 // With rows 18 floats apart the columns fall on the 16 even banks and the second
 // position on the 16 odd ones, so the read is conflict-free.
 constexpr unsigned kRow = 18;
+constexpr int kLoadAux = 0;  // default policy: nontemporal loads measured 3 % slower on the 16-tap stream
 __device__ __forceinline__ unsigned xpad(unsigned l) { return l + 2 * (l >> 4); }
-constexpr unsigned mfma_window_floats(unsigned seglen) { return (kMfmaTile + seglen + 16) / 16 * kRow + kRow; }
-constexpr unsigned mfma_lds_floats(unsigned seglen)
+constexpr unsigned mfma_window_floats(unsigned tile, unsigned seglen) { return (tile + seglen + 16) / 16 * kRow + kRow; }
+constexpr unsigned mfma_lds_floats(unsigned tile, unsigned seglen)
 {
     // padded input window + reversed tap table with 15 leading and >= 33 trailing zeros
-    return mfma_window_floats(seglen) + seglen + 48;
+    return mfma_window_floats(tile, seglen) + seglen + 48;
 }
 
 // Each workgroup walks `tiles_per_block` consecutive tiles.  A "unit" is one
@@ -208,9 +209,10 @@ constexpr unsigned mfma_lds_floats(unsigned seglen)
 // input window of unit u+1 is already on its way from HBM into registers, and
 // is written to LDS once the loop is done (one LDS buffer, two barriers).
 // NIT = staging registers per lane = ceil((tile + segment - 1) / 256).
-template <int NIT>
+template <int NIT, int TPW>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 {
+    constexpr int kMfmaTile = mfma_tile(TPW);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *lds = reinterpret_cast<float *>(smem_raw);
 
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 
     const unsigned seg_cap = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
     float *xs = lds;                                              // padded window
-    float *hr = lds + mfma_window_floats(seg_cap);                // reversed taps
+    float *hr = lds + mfma_window_floats(kMfmaTile, seg_cap);                // reversed taps
 
     const int nseg = (p.nhp + kMfmaSeg - 1) / kMfmaSeg;
     const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
@@ -231,22 +233,37 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
     // A operand: lane holds row i = lane&15, window position kk = lane>>4 of each 4-step
     const unsigned a_base = (lane >> 4) + 15 - (lane & 15);
     // B operand: lane holds column n = lane&15 (outputs 16n..16n+15 of the tile), position kk
-    const unsigned b_base = wave * (1024 / 16 * kRow) + kRow * (lane & 15) + (lane >> 4);
+    const unsigned b_base = wave * (TPW * 256 / 16 * kRow) + kRow * (lane & 15) + (lane >> 4);
 
     float stage[NIT];
 
     struct Unit {
         const float *xrow, *hrow;
-        long sbase;
+        long sbase, tile_start;
+        unsigned chan;
         int seg0, seglen, nstage;
         bool plain;
     };
-    auto describe = [&](long unit) {
+    // (channel, tile in channel, segment) of the unit being described, advanced one unit at
+    // a time: the walk never divides (a 64-bit division per unit per lane costs hundreds of
+    // VALU instructions that would compete with the MFMA stream)
+    unsigned cur_chan = (unsigned)(tile_lo / p.tiles_per_chan);
+    unsigned cur_tile = (unsigned)(tile_lo - (long)cur_chan * p.tiles_per_chan);
+    int cur_seg = 0;
+    auto describe = [&]() {
         Unit d;
-        const long gt = tile_lo + unit / nseg;
-        const int seg = (int)(unit % nseg);
-        const unsigned chan = (unsigned)(gt / p.tiles_per_chan);
-        const long tile_start = (gt - (long)chan * p.tiles_per_chan) * kMfmaTile;
+        const int seg = cur_seg;
+        const unsigned chan = cur_chan;
+        const long tile_start = (long)cur_tile * kMfmaTile;
+        if (++cur_seg == nseg) {
+            cur_seg = 0;
+            if (++cur_tile == p.tiles_per_chan) {
+                cur_tile = 0;
+                ++cur_chan;
+            }
+        }
+        d.chan = chan;
+        d.tile_start = tile_start;
         d.seg0 = seg * kMfmaSeg;
         d.seglen = min((int)p.nhp - d.seg0, kMfmaSeg);
         d.sbase = tile_start - d.seg0 - d.seglen + 1;
@@ -278,14 +295,14 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
                 const int voff = (sb + (int)t) * 4;
 #pragma unroll
                 for (int it = 0; it < NIT; it++)
-                    stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + it * 1024, 0, 0));
+                    stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + it * 1024, 0, kLoadAux));
             } else {
                 // left edge: the offset is unsigned to the hardware, so samples before the
                 // row are sent to an offset that is out of range for every row length
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
                     const int s = sb + (int)t + 256 * it;
-                    stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, s < 0 ? 0x7ffffff0 : s * 4, 0, 0));
+                    stage[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, s < 0 ? 0x7ffffff0 : s * 4, 0, kLoadAux));
                 }
             }
         }
@@ -321,24 +338,25 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
     };
 
     if (nunits <= 0) return;
-    Unit next = describe(0);
+    Unit next = describe();
     fetch(next);
     commit(next, true);
     __syncthreads();
 
-    f32x4 acc[4];
+    f32x4 acc[TPW];
     for (long unit = 0; unit < nunits; unit++) {
+        const Unit cur = next;
         const bool more = unit + 1 < nunits;
         if (more) {
-            next = describe(unit + 1);
+            next = describe();
             fetch(next);
         }
 
-        const int seg = (int)(unit % nseg);
-        const int seglen = min((int)p.nhp - seg * kMfmaSeg, kMfmaSeg);  // multiple of 16
-        if (seg == 0) {
+        const int seglen = cur.seglen;  // multiple of 16
+        const bool last_seg = cur.seg0 + cur.seglen >= (int)p.nhp;
+        if (cur.seg0 == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < TPW; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 
         const float *ap = hr + a_base;
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
             for (int v = 0; v < 4; v++) {
                 const float a = ap[4 * v];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < TPW; q++) {
                     const float b = bp[q * (256 / 16 * kRow) + 4 * v];
                     acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
                 }
@@ -358,19 +376,17 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
             bp += kRow;
         }
 
-        if (seg == nseg - 1) {
+        if (last_seg) {
             // D layout: column n = lane&15, rows 4*(lane>>4) .. +3 -> 4 consecutive outputs per
             // lane; the wave's 64 lanes cover 1 KiB contiguously.
-            const long gt = tile_lo + unit / nseg;
-            const unsigned chan = (unsigned)(gt / p.tiles_per_chan);
-            const long tile_start = (gt - (long)chan * p.tiles_per_chan) * kMfmaTile;
-            float *__restrict__ yrow = p.y + (size_t)chan * p.y_stride;
+            const long tile_start = cur.tile_start;
+            float *__restrict__ yrow = p.y + (size_t)cur.chan * p.y_stride;
             const bool y_vec = (reinterpret_cast<uintptr_t>(yrow) % 16) == 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const long o0 = tile_start + wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+            for (int q = 0; q < TPW; q++) {
+                const long o0 = tile_start + wave * (TPW * 256) + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
                 if (y_vec && o0 + 4 <= (long)p.nxx) {
-                    *reinterpret_cast<f32x4 *>(&yrow[o0]) = acc[q];
+                    __builtin_nontemporal_store(acc[q], reinterpret_cast<f32x4 *>(&yrow[o0]));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
@@ -414,20 +430,26 @@ enum {
 const char *const kVariantName[] = {"fir_f32_mfma16x16x4", "fir_f32_valu_r4g4_b16", "fir_f32_valu_r8g2_b16",
                                     "fir_f64_exact_r4g2_b8"};
 
-int launch_mfma(FirParams<float> p, unsigned nchan, hipStream_t stream)
+// TPW: 256-output MFMA tiles per wave.  4 (4096 outputs per workgroup) for the HBM-bound short
+// filters; 8 for the MFMA-bound long ones (per-tile set-up, barriers and stores amortised
+// over twice the MFMA work, one A-operand read per 8 MFMAs).
+template <int TPW>
+int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream_t stream)
 {
+    constexpr int TILE = mfma_tile(TPW);
     const unsigned seg = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
-    size_t lds = mfma_lds_floats(seg) * sizeof(float);
+    size_t lds = mfma_lds_floats(TILE, seg) * sizeof(float);
     {
         // Resident workgroups per CU are capped by inflating the LDS request.  A short
         // filter is an HBM-bound stream, and the stream is measurably faster with 2-3
         // workgroups (8-12 waves) per CU than with 8; a long filter is MFMA-bound and
         // wants every wave it can get to cover staging and stores.
         const char *env = getenv("DSPMI_FIR_BPC");
-        const int bpc = env && atoi(env) > 0 ? atoi(env) : (p.nhp <= 64 ? 2 : 8);
+        const int bpc = env && atoi(env) > 0 ? atoi(env) : bpc_default;
         const size_t want = (160 * 1024) / bpc - 512;
         if (want > lds) lds = want;
     }
+    p.tiles_per_chan = (p.nxx + TILE - 1) / TILE;
     const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
     if (tiles == 0) return DSPMI_OK;
     if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
@@ -437,17 +459,25 @@ int launch_mfma(FirParams<float> p, unsigned nchan, hipStream_t stream)
     unsigned tpb = (unsigned)(tiles / 16384);
     p.tiles_per_block = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
-    auto k17 = fir_mfma_kernel<(kMfmaTile + 256 + 255) / 256>;
-    auto k24 = fir_mfma_kernel<(kMfmaTile + kMfmaSeg + 255) / 256>;
+    auto k_small = fir_mfma_kernel<(TILE + 256 + 255) / 256, TPW>;      // segments up to 256 taps
+    auto k_large = fir_mfma_kernel<(TILE + kMfmaSeg + 255) / 256, TPW>;  // up to kMfmaSeg taps
     static bool attr_done = false;
     if (!attr_done) {
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k17), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k24), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_large), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL(seg <= 256 ? k17 : k24, dim3(blocks), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(seg <= 256 ? k_small : k_large, dim3(blocks), dim3(256), lds, stream, p);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
+}
+
+int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
+{
+    const char *env = getenv("DSPMI_FIR_TPW");
+    const int tpw = env && atoi(env) > 0 ? atoi(env) : 4;  // 8 measured no faster at 127 taps
+    if (tpw == 8) return launch_mfma_t<8>(p, nchan, 4, stream);
+    return launch_mfma_t<4>(p, nchan, p.nhp <= 64 ? 2 : 8, stream);
 }
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
@@ -522,7 +552,6 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     if constexpr (sizeof(T) == 4) {
         if (pl->variant == V_F32_MFMA) {
-            p.tiles_per_chan = (nxx + kMfmaTile - 1) / kMfmaTile;
             return launch_mfma(p, nchan, s);
         }
         if (pl->variant == V_F32_SHORT) {
