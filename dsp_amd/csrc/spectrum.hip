@@ -28,7 +28,26 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-constexpr int kMaxPerLane = 64;  // up to 4096 bins per frame in registers
+// sin / cos of a running angle.  The reference evaluates libm's sin/cos on the accumulated,
+// never-reduced angle (tonegen/tonegen.c:36-37; it reaches ~1e6 rad after a million samples),
+// where a generic device sin falls into its slow large-argument path on every lane.  The angle
+// is first brought to [-pi, pi] with a three-constant Cody-Waite reduction by 2*pi (exact to
+// ~1e-17 for |w| < 2^26 * 2*pi), then the library routine runs on the small argument.  The
+// value agrees with libm's to about an ulp of double, far below the f32 the sample is stored in.
+__device__ __forceinline__ double reduce_2pi(double w)
+{
+    const double inv = 0.15915494309189533577;           // 1 / (2 pi)
+    const double c1 = 6.28318530717958623200e+00;         // 2 pi, leading 53 bits
+    const double c2 = 2.44929359829470641435e-16;         // next bits
+    const double c3 = -5.989539619436679e-33;             // and the next
+    const double k = rint(w * inv);
+    double r = fma(-k, c1, w);
+    r = fma(-k, c2, r);
+    r = fma(-k, c3, r);
+    return r;
+}
+__device__ __forceinline__ double tone_sin(double w) { return sin(fabs(w) < 3.2 ? w : reduce_2pi(w)); }
+__device__ __forceinline__ double tone_cos(double w) { return cos(fabs(w) < 3.2 ? w : reduce_2pi(w)); }
 
 // mode 0: ps = |X| / sum if sum > 1e-5 else |X|      (fft/src/main.c:120-141)
 // mode 1: ps = |X| / sum                             (alsa/main.c:473-487)
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(64) void tonegen_kernel(float *__restrict__ x, size
 #pragma unroll
             for (int j = 0; j < MAXT; j++) {
                 if (j < (int)ntone) {
-                    v += use_sin ? sin(wl[j]) : al[j] * cos(wl[j] + pl[j]);
+                    v += use_sin ? tone_sin(wl[j]) : al[j] * tone_cos(wl[j] + pl[j]);
                     if (base + i < n) wl[j] += dwl[j];
                 }
             }
@@ -147,6 +166,86 @@ __global__ __launch_bounds__(64) void tonegen_kernel(float *__restrict__ x, size
 #pragma unroll
     for (int j = 0; j < MAXT; j++)
         if (live && j < (int)ntone) w[(size_t)c * ntone + j] = wl[j];
+}
+
+// ---- the same generator, parallel in time ---------------------------------------------
+// The recurrence w += dw is sequential, but it is cheap next to the cosines.  Pass 1 walks it
+// alone (one lane per channel and tone) and records the running angle at the start of every
+// 256-sample chunk; pass 2 gives every chunk to its own lane, which replays the same 256
+// additions from the recorded angle -- bit for bit the values the sequential kernel sees --
+// and evaluates the tones.  64 consecutive chunks of a channel form a workgroup, transposed
+// through LDS so the stores are contiguous.
+constexpr unsigned kToneChunk = 256;
+
+__global__ __launch_bounds__(64) void tonegen_phase_kernel(double *__restrict__ w, const double *__restrict__ dw,
+                                                           double *__restrict__ wstart, unsigned n, unsigned nseq)
+{
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;  // (channel, tone) pair
+    if (s >= nseq) return;
+    const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
+    double a = w[s];
+    const double d = dw[s];
+    for (unsigned c = 0; c < nchunk; c++) {
+        wstart[(size_t)s * nchunk + c] = a;
+        const unsigned len = min(kToneChunk, n - c * kToneChunk);
+        if (len == kToneChunk) {
+            // a bare chain of dependent additions: nothing but the adder's latency per sample
+#pragma unroll
+            for (unsigned i = 0; i < kToneChunk; i++) {
+                a += d;
+                asm volatile("" : "+v"(a));  // keep the additions separate and in order
+            }
+        } else {
+            for (unsigned i = 0; i < len; i++) a += d;
+        }
+    }
+    w[s] = a;
+}
+
+__global__ __launch_bounds__(64) void tonegen_chunk_kernel(float *__restrict__ x, size_t x_stride, unsigned n,
+                                                           unsigned ntone, const double *__restrict__ wstart,
+                                                           const double *__restrict__ dw, const double *__restrict__ amp,
+                                                           const double *__restrict__ phi, int use_sin)
+{
+    __shared__ float tile[64][65];
+    const unsigned lane = threadIdx.x;
+    const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
+    const unsigned groups = (nchunk + 63) / 64;  // workgroups per channel
+    const unsigned chan = blockIdx.x / groups;
+    const unsigned chunk = (blockIdx.x - chan * groups) * 64 + lane;
+    const bool live = chunk < nchunk;
+    constexpr int MAXT = 8;
+    double wl[MAXT], dwl[MAXT], al[MAXT], pl[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; j++) {
+        const bool on = live && j < (int)ntone;
+        const size_t s = (size_t)chan * ntone + j;
+        wl[j] = on ? wstart[s * nchunk + chunk] : 0.0;
+        dwl[j] = on ? dw[s] : 0.0;
+        al[j] = on ? amp[s] : 0.0;
+        pl[j] = on ? phi[s] : 0.0;
+    }
+    float *xrow = x + (size_t)chan * x_stride;
+    const size_t first = (size_t)(blockIdx.x - chan * groups) * 64 * kToneChunk;  // sample of lane 0, step 0
+    for (unsigned base = 0; base < kToneChunk; base += 64) {
+        for (unsigned i = 0; i < 64; i++) {
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < MAXT; j++) {
+                if (j < (int)ntone) {
+                    v += use_sin ? tone_sin(wl[j]) : al[j] * tone_cos(wl[j] + pl[j]);
+                    wl[j] += dwl[j];
+                }
+            }
+            tile[lane][i] = (float)v;
+        }
+        __syncthreads();
+        for (unsigned r = 0; r < 64; r++) {
+            const size_t smp = first + (size_t)r * kToneChunk + base + lane;
+            if (smp < n) xrow[smp] = tile[r][lane];
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -174,14 +273,30 @@ int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigne
     return DSPMI_OK;
 }
 
+size_t dspmi_tonegen_work_bytes(unsigned n, unsigned nchan, unsigned ntone)
+{
+    return (size_t)nchan * ntone * ((n + kToneChunk - 1) / kToneChunk) * sizeof(double);
+}
+
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
-                      const double *amp, const double *phi, int use_sin, void *stream)
+                      const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
 {
     if (n == 0 || nchan == 0) return DSPMI_OK;
     if (!x || !w || !dw || (!use_sin && (!amp || !phi))) return dspmi::fail(DSPMI_EINVAL, "tonegen: null buffer");
     if (ntone == 0 || ntone > 8) return dspmi::fail(DSPMI_ENOSYS, "tonegen: 1..8 tones per channel on the device (got %u)", ntone);
     if (x_stride < n) return dspmi::fail(DSPMI_EINVAL, "tonegen: x_stride < n");
     if (use_sin && (!amp || !phi)) amp = phi = dw;  // never read in the sine form
+    if (work && work_bytes >= dspmi_tonegen_work_bytes(n, nchan, ntone)) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        double *wstart = static_cast<double *>(work);
+        const unsigned nseq = nchan * ntone;
+        const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
+        hipLaunchKernelGGL(tonegen_phase_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, wstart, n, nseq);
+        hipLaunchKernelGGL(tonegen_chunk_kernel, dim3(nchan * ((nchunk + 63) / 64)), dim3(64), 0, s, x, x_stride, n, ntone,
+                           wstart, dw, amp, phi, use_sin);
+        DSPMI_HIP(hipGetLastError());
+        return DSPMI_OK;
+    }
     hipLaunchKernelGGL(tonegen_kernel, dim3((nchan + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), x, x_stride, n,
                        nchan, ntone, w, dw, amp, phi, use_sin);
     DSPMI_HIP(hipGetLastError());

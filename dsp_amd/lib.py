@@ -57,7 +57,8 @@ _SIGS = {
     "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
     "dspmi_fft_exec_r2c_spectrum": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
-    "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "dspmi_tonegen_work_bytes": (_sz, [_u, _u, _u]),
+    "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),
@@ -265,14 +266,22 @@ class ToneGen:
         self.phi = torch.from_numpy(np.ascontiguousarray(phis)).to(device)
         self.w = torch.zeros_like(self.dw)
 
-    def read(self, n, out=None):
+    def read(self, n, out=None, sequential=False):
+        """Next n samples of every channel.  sequential=True walks each channel with one lane
+        (no scratch); the default replays recorded chunk phases in parallel -- same bits."""
         import torch
         if out is None:
             out = torch.empty((self.nchan, n), dtype=torch.float32, device=self.w.device)
         assert out.shape == (self.nchan, n) and out.stride(1) == 1
+        wp, wb = None, 0
+        if not sequential:
+            wb = lib().dspmi_tonegen_work_bytes(n, self.nchan, self.ntone)
+            if getattr(self, "_work", None) is None or self._work.numel() < wb:
+                self._work = torch.empty(wb, dtype=torch.uint8, device=self.w.device)
+            wp = self._work.data_ptr()
         _check(lib().dspmi_tonegen_f32(out.data_ptr(), out.stride(0) if self.nchan > 1 else n, n, self.nchan, self.ntone,
                                        self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
-                                       int(self.use_sin), _stream()), "tonegen")
+                                       int(self.use_sin), wp, wb, _stream()), "tonegen")
         return out
 
 

@@ -185,10 +185,15 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
  * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from
  * call to call.  use_sin != 0 selects the unit-amplitude sine form of fft/src/main.c:281-290
- * (amp and phi unused).  ntone <= 8. */
+ * (amp and phi unused).  ntone <= 8.
+ * work: optional device scratch of dspmi_tonegen_work_bytes(n, nchan, ntone) bytes; with it the
+ * call is parallel in time as well as over channels (the running angle at the start of every
+ * 256-sample chunk is recorded first, then the chunks are replayed independently: the same
+ * additions, so the same bits); without it (NULL) one lane walks each channel. */
+size_t dspmi_tonegen_work_bytes(unsigned n, unsigned nchan, unsigned ntone);
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
                       double *w, const double *dw, const double *amp, const double *phi,
-                      int use_sin, void *stream);
+                      int use_sin, void *work, size_t work_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Host drop-in wrappers (reference signatures; host double buffers)         */

@@ -51,6 +51,11 @@ def test_tonegen_matches_recurrence_and_continues():
         want = t.read(1333)
         got = np.concatenate([a[c], b[c]])
         assert np.abs(got - want.astype(np.float32)).max() <= 2e-7 * 1.5   # f32 rounding of a double sum
+    # the time-parallel form replays the same additions: identical bits to the one-lane walk
+    g_seq, g_par = dsp_amd.ToneGen(fs, freqs, amps, phis), dsp_amd.ToneGen(fs, freqs, amps, phis)
+    for n in (1000, 333, 70000):
+        assert torch.equal(g_seq.read(n, sequential=True), g_par.read(n))
+    assert torch.equal(g_seq.w, g_par.w)
     # the sine form of fft/src/main.c:265-291
     g2 = dsp_amd.ToneGen(fs, [[100.0, 12000.0]], use_sin=True)
     got = g2.read(4096).cpu().numpy()[0]

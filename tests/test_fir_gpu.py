@@ -194,3 +194,32 @@ def test_many_tiles_per_workgroup_walk(nh):
             want = oracle.fir_batch_f32(seg, h, len(seg))[0][lo - max(0, lo - nh):]
             got = y[c, lo:lo + 10000].cpu().numpy()
             assert rel_l2(got, want) <= TOL_FIR, (c, lo)
+
+
+def test_degenerate_shapes_through_the_abi():
+    """Empty and ragged calls: no output, no channel, more taps than samples, zero-length input."""
+    import ctypes as C
+    L = dsp_amd.lib()
+    h = np.arange(1, 6, dtype=np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    x = torch.ones((2, 3), device="cuda")
+    # nxx = 0 and nchan = 0 are no-ops that succeed
+    assert L.dspmi_fir_exec_f32(plan._h, None, 0, 0, x.data_ptr(), 3, 3, 2, None, 0, 0, None) == 0
+    assert L.dspmi_fir_exec_f32(plan._h, None, 0, 5, None, 0, 0, 0, None, 0, 0, None) == 0
+    # more taps than samples, output longer than nx + nh: the tail is zeros
+    y = plan.exec(x, 12).cpu().numpy()
+    want = oracle.fir_batch_f32(np.ones((2, 3), np.float32), h, 12)
+    np.testing.assert_allclose(y, want, rtol=0, atol=1e-6)
+    assert not y[:, 7:].any()
+    # nx = 0: every output is an empty sum
+    y0 = torch.full((1, 4), 7.0, device="cuda")
+    assert L.dspmi_fir_exec_f32(plan._h, y0.data_ptr(), 4, 4, None, 0, 0, 1, None, 0, 0, None) == 0
+    torch.cuda.synchronize()
+    assert not y0.cpu().numpy().any()
+    # argument errors come back as -EINVAL with a message, nothing is launched
+    assert L.dspmi_fir_exec_f32(plan._h, y0.data_ptr(), 2, 4, x.data_ptr(), 3, 3, 1, None, 0, 0, None) == -22
+    assert b"stride" in L.dspmi_last_error()
+    # host wrappers with empty tap sets / single samples
+    assert np.array_equal(dsp_amd.conv0(np.array([2.0]), np.array([3.0])), np.array([6.0]))
+    assert np.array_equal(dsp_amd.conv1(np.array([2.0]), np.array([3.0])), np.array([0.0]))
+    assert np.array_equal(dsp_amd.convolve(np.array([1.0, 2.0]), np.array([1.0]), 5), np.array([1.0, 2.0, 0, 0, 0]))
