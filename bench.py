@@ -296,7 +296,7 @@ def cpu_baseline_fir(nh, target_s=8.0):
     for _ in range(reps):
         L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
     dt = time.perf_counter() - t0
-    return {"value": round(reps * nx / dt / 1e9, 5), "unit": "Gsamples/s", "cores": 1, "kind": "port",
+    return {"value": float("%.4g" % (reps * nx / dt / 1e9)), "unit": "Gsamples/s", "cores": 1, "kind": "port",
             "sample": "%d blocks of %d samples, %d taps (double, gcc -O3, 1 thread)" % (reps, nx, nh)}
 
 
