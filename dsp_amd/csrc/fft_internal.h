@@ -16,6 +16,9 @@ typedef int (*fft_launch_fn)(const void *in, void *out, const void *tw, size_t b
 // Real input through this N-point complex kernel: in = batch frames of 2N reals; epilogue 1
 // writes bins 0..N (N+1 complex per frame), epilogue 2 writes the magnitude spectrum over nbin
 // (N or N+1) bins normalised per `mode` (DSPMI_PS_*).  tw2n = exp(-2 pi i k / 2N), k < N.
+// epilogue | kR2cSourceS16x2: `in` holds 2N interleaved 16-bit stereo frames per transform
+// instead of 2N floats; a frame enters as (left + right) / 2.
+constexpr int kR2cSourceS16x2 = 0x100;
 typedef int (*fft_r2c_launch_fn)(const void *in, void *out, const void *tw, const void *tw2n, size_t batch, int epilogue,
                                  unsigned nbin, int mode, float scale, int num_cu, hipStream_t s);
 

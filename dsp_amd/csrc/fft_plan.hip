@@ -253,6 +253,15 @@ std::vector<C<T>> chirp(unsigned n)
     return c;
 }
 
+// interleaved 16-bit stereo frames -> mono floats, (left + right) / 2 (alsa/main.c:464-468)
+__global__ __launch_bounds__(256) void s16x2_to_mono_kernel(float *__restrict__ mono, const int *__restrict__ frames, size_t total)
+{
+    GRID_STRIDE(i, total) {
+        const int f = frames[i];
+        mono[i] = (float)((short)(f & 0xffff) + (f >> 16)) * 0.5f;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -274,8 +283,8 @@ struct dspmi_fft_plan {
     const dspmi::FftKernel *kern_M = nullptr;
     void *tw_M = nullptr, *chirp = nullptr, *filt = nullptr;
     // scratch, grown on demand (allocation happens in exec only when a batch outgrows it)
-    void *work[3] = {nullptr, nullptr, nullptr};  // 0: Bluestein, 1: real transforms, 2: spectrum bins
-    size_t work_bytes[3] = {0, 0, 0};
+    void *work[4] = {nullptr, nullptr, nullptr, nullptr};  // 0: Bluestein, 1: real transforms, 2: spectrum bins, 3: converted input
+    size_t work_bytes[4] = {0, 0, 0, 0};
     char name[64] = "";
 };
 
@@ -486,7 +495,7 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
 int dspmi_fft_destroy(dspmi_fft_t plan)
 {
     if (!plan) return DSPMI_OK;
-    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1], plan->work[2]};
+    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1], plan->work[2], plan->work[3]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete plan;
@@ -546,6 +555,32 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
     rc = r2c_typed<float>(plan, in, plan->work[2], batch, s);
     if (rc != DSPMI_OK) return rc;
     return dspmi_power_spectrum_f32(ps, plan->work[2], nbin, n / 2 + 1, batch, mode, scale, stream);
+}
+
+int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float *ps, size_t batch, unsigned nbin, int mode,
+                                      float scale, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: null plan");
+    if (plan->precision != DSPMI_F32) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_r2c_spectrum_s16x2: f32 plans only");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !ps) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: null buffer");
+    if (reinterpret_cast<uintptr_t>(in) & 7)
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: input must be 8-byte aligned");
+    if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: mode must be 0, 1 or 2");
+    const unsigned n = plan->n;
+    if (nbin == 0 || nbin > n / 2 + 1) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: nbin must be 1..n/2+1");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->kern_half && plan->kern_half->fn_r2c && nbin >= n / 2)
+        return plan->kern_half->fn_r2c(in, ps, plan->tw_half, plan->tw_n, batch, 2 | dspmi::kR2cSourceS16x2, nbin, mode, scale,
+                                       plan->num_cu, s);
+    // any other length: convert to mono floats first
+    const size_t total = batch * (size_t)n;
+    int rc = ensure_work(plan, 3, total * sizeof(float));
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(s16x2_to_mono_kernel, dim3(ew_grid(total, plan->num_cu)), dim3(256), 0, s,
+                       static_cast<float *>(plan->work[3]), reinterpret_cast<const int *>(in), total);
+    DSPMI_HIP(hipGetLastError());
+    return dspmi_fft_exec_r2c_spectrum(plan, plan->work[3], ps, batch, nbin, mode, scale, stream);
 }
 
 const char *dspmi_fft_variant(dspmi_fft_t plan)

@@ -385,7 +385,7 @@ template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, int
 __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T> *in, void *out_raw,
                                                                       const C<T> *__restrict__ tw,
                                                                       const C<T> *__restrict__ tw2n, size_t batch,
-                                                                      unsigned nbin, int mode, float scale)
+                                                                      unsigned nbin, int mode, float scale, int pcm)
 {
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
     constexpr int P = N / NT;
@@ -417,6 +417,15 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
             for (int r = 0; r < R0; r++) {
                 C<T> q = {T(0), T(0)};
                 if (active) q = nt_load(&src[tl + NT * b + r * (N / R0)]);
+                if constexpr (sizeof(T) == 4) {
+                    // pcm: the same 8 bytes are two interleaved 16-bit stereo frames, each
+                    // entering as (left + right) / 2 (alsa/main.c:464-468)
+                    if (pcm) {
+                        const int f0 = __float_as_int(q.re), f1 = __float_as_int(q.im);
+                        q.re = (float)((short)(f0 & 0xffff) + (f0 >> 16)) * 0.5f;
+                        q.im = (float)((short)(f1 & 0xffff) + (f1 >> 16)) * 0.5f;
+                    }
+                }
                 v[b * R0 + r] = q;
             }
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
@@ -686,6 +695,8 @@ int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size
         attr_set = true;
     }
     if (batch == 0) return DSPMI_OK;
+    const int pcm = (epilogue & dspmi::kR2cSourceS16x2) != 0;
+    epilogue &= 0xff;
     const size_t nfb = (batch + FPB - 1) / FPB;
     size_t per_cu = (160 * 1024) / lds;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
@@ -693,7 +704,7 @@ int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size
     size_t grid = (size_t)num_cu * per_cu;
     if (grid > nfb) grid = nfb;
     hipLaunchKernelGGL(epilogue == 1 ? k1 : k2, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), out,
-                       static_cast<const C<T> *>(tw), static_cast<const C<T> *>(tw2n), batch, nbin, mode, scale);
+                       static_cast<const C<T> *>(tw), static_cast<const C<T> *>(tw2n), batch, nbin, mode, scale, pcm);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }

@@ -80,7 +80,10 @@ __device__ __forceinline__ T mac(T acc, T h, T v)
 }
 
 // SEG: taps handled per LDS staging round (bounds the LDS footprint for any nh).
-template <typename T, int R, int G, int NHB, int SEG, bool EXACT, bool DESC>
+// PCM: x and y hold interleaved 16-bit stereo frames (one 32-bit word per frame) instead of
+// T: a frame enters as (left + right) / 2 and a result leaves as (int16_t)value in both
+// channels, the conversions of alsa/main.c:527-528,533-539.
+template <typename T, int R, int G, int NHB, int SEG, bool EXACT, bool DESC, bool PCM = false>
 __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
 {
     constexpr int TILE = 256 * R * G;
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
     const long tile_start = (long)tile * TILE;
 
     const T *__restrict__ xrow = p.x + (size_t)chan * p.x_stride;
-    const T *__restrict__ hrow = p.hist ? p.hist + (size_t)chan * p.hist_stride : nullptr;
+    const int *__restrict__ xpcm = reinterpret_cast<const int *>(p.x) + (size_t)chan * p.x_stride;
+    const T *__restrict__ hrow = (!PCM && p.hist) ? p.hist + (size_t)chan * p.hist_stride : nullptr;
     const bool drop_first = (p.flags & DSPMI_FIR_DROP_FIRST) != 0;
     const long nx = p.nx, nh = p.nh;
 
@@ -122,7 +126,14 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
             const long s = sbase + l;
             T v = T(0);
             if (s >= 0) {
-                if (s < nx && !(drop_first && s == 0)) v = xrow[s];
+                if (s < nx && !(drop_first && s == 0)) {
+                    if constexpr (PCM) {
+                        const int f = xpcm[s];  // left in the low half, right in the high half
+                        v = ((T)(short)(f & 0xffff) + (T)(short)(f >> 16)) / T(2);
+                    } else {
+                        v = xrow[s];
+                    }
+                }
             } else if (hrow && s >= 1 - nh) {
                 v = hrow[nh - 1 + s];
             }
@@ -160,6 +171,23 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
     }
 
     // ---- store ----
+    if constexpr (PCM) {
+        int *__restrict__ ypcm = reinterpret_cast<int *>(p.y) + (size_t)chan * p.y_stride;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const long o0 = tile_start + g * (256 * R) + t * R;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                // (int16_t)value as the reference's x86 build performs it: truncate toward zero
+                // to 32 bits (anything outside that range, or NaN, becomes 0x80000000), keep
+                // the low 16 bits
+                const T a = acc[g][r];
+                const unsigned v = (a > T(-2147483649.0) && a < T(2147483648.0)) ? ((unsigned)(int)a & 0xffffu) : 0u;
+                if (o0 + r < (long)p.nxx) ypcm[o0 + r] = (int)(v | (v << 16));
+            }
+        }
+        return;
+    }
     T *__restrict__ yrow = p.y + (size_t)chan * p.y_stride;
     const bool y_vec = (reinterpret_cast<uintptr_t>(yrow) % (4 * sizeof(T))) == 0;
 #pragma unroll
@@ -483,13 +511,13 @@ int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
-template <typename T, int R, int G, int NHB, bool EXACT, bool DESC>
+template <typename T, int R, int G, int NHB, bool EXACT, bool DESC, bool PCM = false>
 int launch(const FirParams<T> &p, unsigned nchan, hipStream_t stream)
 {
     constexpr int TILE = 256 * R * G;
     const unsigned seg = p.nhp < (unsigned)kSeg ? p.nhp : (unsigned)kSeg;
     const size_t lds = lds_elems<R>(TILE + seg + 8) * sizeof(T);
-    auto kern = fir_direct_kernel<T, R, G, NHB, kSeg, EXACT, DESC>;
+    auto kern = fir_direct_kernel<T, R, G, NHB, kSeg, EXACT, DESC, PCM>;
     if (lds > 48 * 1024)
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -613,6 +641,34 @@ int dspmi_fir_exec_f64(dspmi_fir_t plan, double *y, size_t y_stride, unsigned nx
 {
     return exec<double>(plan, y, y_stride, nxx, x, x_stride, nx, nchan, hist, hist_stride, flags, stream, DSPMI_F64,
                         false);
+}
+
+int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, const int16_t *in, size_t in_stride,
+                         unsigned nsampl, unsigned nblock, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: null plan");
+    if (plan->precision != DSPMI_F64)
+        return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: needs a double-precision plan (results are exact integers)");
+    if (nsampl == 0 || nblock == 0) return DSPMI_OK;
+    if (!out || !in) return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: null buffer");
+    if (out_stride < nsampl || in_stride < nsampl)
+        return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: stride smaller than the block length");
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 3)
+        return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: buffers must be 4-byte aligned (one stereo frame)");
+    {
+        // a workgroup reads the nh-1 frames before its tile after another may have overwritten them
+        const char *a = reinterpret_cast<const char *>(in), *b = reinterpret_cast<const char *>(out);
+        const size_t span_in = ((size_t)(nblock - 1) * in_stride + nsampl) * 4;
+        const size_t span_out = ((size_t)(nblock - 1) * out_stride + nsampl) * 4;
+        if (a < b + span_out && b < a + span_in) return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: in and out overlap");
+    }
+    FirParams<double> p;
+    p.y = reinterpret_cast<double *>(out); p.x = reinterpret_cast<const double *>(in); p.hist = nullptr;
+    p.taps = static_cast<const double *>(plan->taps_dev);
+    p.y_stride = out_stride; p.x_stride = in_stride; p.hist_stride = 0;
+    p.nxx = nsampl; p.nx = nsampl; p.nh = plan->nh; p.nhp = plan->nhp; p.flags = 0;
+    p.tiles_per_chan = (nsampl + 2047) / 2048;
+    return launch<double, 4, 2, 8, true, false, true>(p, nblock, static_cast<hipStream_t>(stream));
 }
 
 const char *dspmi_fir_variant(dspmi_fir_t plan)

@@ -13,6 +13,9 @@
 //    the stores to the channel-major signal are coalesced.
 #include "common.h"
 
+#include <cstdint>
+#include <type_traits>
+
 #include <cmath>
 
 namespace {
@@ -124,12 +127,27 @@ __global__ __launch_bounds__(256) void power_spectrum_long_kernel(float *__restr
 // state: [nchan][ntone] running angles (double, updated); dw, amp, phi: [nchan][ntone].
 // 64 channels per workgroup of 64 lanes; each lane advances its channel 64 samples, the
 // tile is transposed through LDS and written as 64 rows of 256 contiguous bytes.
-__global__ __launch_bounds__(64) void tonegen_kernel(float *__restrict__ x, size_t x_stride, unsigned n, unsigned nchan,
+// O = float: samples as floats; O = int: one interleaved 16-bit stereo frame per sample, both
+// channels (int16_t)value (tonegen/main.c:14-24).
+template <typename O>
+__device__ __forceinline__ O tone_out(double v)
+{
+    if constexpr (std::is_floating_point<O>::value) {
+        return (O)v;
+    } else {
+        // the cast as an x86 build performs it: truncate to 32 bits (out of range -> 0x80000000), low half
+        const unsigned h = (v > -2147483649.0 && v < 2147483648.0) ? ((unsigned)(int)v & 0xffffu) : 0u;
+        return (O)(h | (h << 16));
+    }
+}
+
+template <typename O>
+__global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned nchan,
                                                      unsigned ntone, double *__restrict__ w, const double *__restrict__ dw,
                                                      const double *__restrict__ amp, const double *__restrict__ phi,
                                                      int use_sin)
 {
-    __shared__ float tile[64][65];
+    __shared__ O tile[64][65];
     const unsigned lane = threadIdx.x;
     const unsigned c = blockIdx.x * 64 + lane;
     const bool live = c < nchan;
@@ -154,7 +172,7 @@ __global__ __launch_bounds__(64) void tonegen_kernel(float *__restrict__ x, size
                     if (base + i < n) wl[j] += dwl[j];
                 }
             }
-            tile[lane][i] = (float)v;
+            tile[lane][i] = tone_out<O>(v);
         }
         __syncthreads();
         for (unsigned r = 0; r < 64; r++) {
@@ -202,12 +220,13 @@ __global__ __launch_bounds__(64) void tonegen_phase_kernel(double *__restrict__ 
     w[s] = a;
 }
 
-__global__ __launch_bounds__(64) void tonegen_chunk_kernel(float *__restrict__ x, size_t x_stride, unsigned n,
+template <typename O>
+__global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, size_t x_stride, unsigned n,
                                                            unsigned ntone, const double *__restrict__ wstart,
                                                            const double *__restrict__ dw, const double *__restrict__ amp,
                                                            const double *__restrict__ phi, int use_sin)
 {
-    __shared__ float tile[64][65];
+    __shared__ O tile[64][65];
     const unsigned lane = threadIdx.x;
     const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
     const unsigned groups = (nchunk + 63) / 64;  // workgroups per channel
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(64) void tonegen_chunk_kernel(float *__restrict__ x
         al[j] = on ? amp[s] : 0.0;
         pl[j] = on ? phi[s] : 0.0;
     }
-    float *xrow = x + (size_t)chan * x_stride;
+    O *xrow = x + (size_t)chan * x_stride;
     const size_t first = (size_t)(blockIdx.x - chan * groups) * 64 * kToneChunk;  // sample of lane 0, step 0
     for (unsigned base = 0; base < kToneChunk; base += 64) {
         for (unsigned i = 0; i < 64; i++) {
@@ -237,7 +256,7 @@ __global__ __launch_bounds__(64) void tonegen_chunk_kernel(float *__restrict__ x
                     wl[j] += dwl[j];
                 }
             }
-            tile[lane][i] = (float)v;
+            tile[lane][i] = tone_out<O>(v);
         }
         __syncthreads();
         for (unsigned r = 0; r < 64; r++) {
@@ -278,8 +297,13 @@ size_t dspmi_tonegen_work_bytes(unsigned n, unsigned nchan, unsigned ntone)
     return (size_t)nchan * ntone * ((n + kToneChunk - 1) / kToneChunk) * sizeof(double);
 }
 
-int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
-                      const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
+}  // extern "C"
+
+namespace {
+
+template <typename O>
+int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
+                const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
 {
     if (n == 0 || nchan == 0) return DSPMI_OK;
     if (!x || !w || !dw || (!use_sin && (!amp || !phi))) return dspmi::fail(DSPMI_EINVAL, "tonegen: null buffer");
@@ -292,15 +316,33 @@ int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, uns
         const unsigned nseq = nchan * ntone;
         const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
         hipLaunchKernelGGL(tonegen_phase_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, wstart, n, nseq);
-        hipLaunchKernelGGL(tonegen_chunk_kernel, dim3(nchan * ((nchunk + 63) / 64)), dim3(64), 0, s, x, x_stride, n, ntone,
+        hipLaunchKernelGGL(tonegen_chunk_kernel<O>, dim3(nchan * ((nchunk + 63) / 64)), dim3(64), 0, s, x, x_stride, n, ntone,
                            wstart, dw, amp, phi, use_sin);
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
-    hipLaunchKernelGGL(tonegen_kernel, dim3((nchan + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), x, x_stride, n,
+    hipLaunchKernelGGL(tonegen_kernel<O>, dim3((nchan + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), x, x_stride, n,
                        nchan, ntone, w, dw, amp, phi, use_sin);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
+                      const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
+{
+    return tonegen_run<float>(x, x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, work, work_bytes, stream);
+}
+
+int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
+                        const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
+{
+    if (reinterpret_cast<uintptr_t>(x) & 3) return dspmi::fail(DSPMI_EINVAL, "tonegen: output must be 4-byte aligned");
+    return tonegen_run<int>(reinterpret_cast<int *>(x), x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, work, work_bytes,
+                            stream);
 }
 
 }  // extern "C"

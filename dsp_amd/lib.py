@@ -44,6 +44,7 @@ _SIGS = {
     "dspmi_fir_destroy": (C.c_int, [_vp]),
     "dspmi_fir_exec_f32": (C.c_int, [_vp, _vp, _sz, _u, _vp, _sz, _u, _u, _vp, _sz, _u, _vp]),
     "dspmi_fir_exec_f64": (C.c_int, [_vp, _vp, _sz, _u, _vp, _sz, _u, _u, _vp, _sz, _u, _vp]),
+    "dspmi_fir_exec_s16x2": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp]),
     "dspmi_fir_variant": (C.c_char_p, [_vp]),
     "dspmi_fft_create": (C.c_int, [C.POINTER(_vp), _u, C.c_int, C.c_int]),
     "dspmi_fft_destroy": (C.c_int, [_vp]),
@@ -56,9 +57,11 @@ _SIGS = {
     "dspmi_ols_fft_length": (_u, [_vp]),
     "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
     "dspmi_fft_exec_r2c_spectrum": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
+    "dspmi_fft_exec_r2c_spectrum_s16x2": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
     "dspmi_tonegen_work_bytes": (_sz, [_u, _u, _u]),
     "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "dspmi_tonegen_s16x2": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),
@@ -147,6 +150,22 @@ class FirPlan:
                   x.data_ptr(), x.stride(0) if nchan > 1 else nx, nx, nchan, hp, hs, flags, _stream()), "fir_exec")
         return y
 
+    def exec_s16x2(self, frames, out=None):
+        """frames: [nblock, nsampl, 2] int16 CUDA tensor of stereo capture blocks; every block is
+        filtered from zero state and comes back as int16 in both channels (f64 plans only)."""
+        import torch
+        assert frames.is_cuda and frames.dtype == torch.int16 and frames.dim() == 3 and frames.shape[2] == 2
+        assert frames.stride(2) == 1 and frames.stride(1) == 2 and frames.stride(0) % 2 == 0
+        nblock, nsampl = frames.shape[0], frames.shape[1]
+        if out is None:
+            out = torch.empty_like(frames)
+        assert out.is_cuda and out.dtype == torch.int16 and out.shape == frames.shape
+        assert out.stride(2) == 1 and out.stride(1) == 2 and out.stride(0) % 2 == 0
+        _check(lib().dspmi_fir_exec_s16x2(self._h, out.data_ptr(), out.stride(0) // 2 if nblock > 1 else nsampl,
+                                          frames.data_ptr(), frames.stride(0) // 2 if nblock > 1 else nsampl,
+                                          nsampl, nblock, _stream()), "fir_exec_s16x2")
+        return out
+
     def close(self):
         if self._h:
             lib().dspmi_fir_destroy(self._h)
@@ -209,6 +228,21 @@ class FftPlan:
             out = torch.empty(x.shape[:-1] + (nbin,), dtype=torch.float32, device=x.device)
         _check(lib().dspmi_fft_exec_r2c_spectrum(self._h, x.data_ptr(), out.data_ptr(), batch, nbin, mode, scale, _stream()),
                "fft_exec_r2c_spectrum")
+        return out
+
+    def r2c_spectrum_s16x2(self, frames, nbin=None, mode=1, scale=1.0, out=None):
+        """frames: [batch, n, 2] int16 stereo blocks -> [batch, nbin] magnitude spectrum of the mono mix."""
+        import torch
+        assert frames.is_cuda and frames.dtype == torch.int16 and frames.is_contiguous()
+        assert frames.dim() == 3 and frames.shape[1] == self.n and frames.shape[2] == 2
+        batch = frames.shape[0]
+        if nbin is None:
+            nbin = self.n // 2
+        if out is None:
+            out = torch.empty((batch, nbin), dtype=torch.float32, device=frames.device)
+        assert out.is_contiguous() and out.shape == (batch, nbin) and out.dtype == torch.float32
+        _check(lib().dspmi_fft_exec_r2c_spectrum_s16x2(self._h, frames.data_ptr(), out.data_ptr(), batch, nbin, mode, scale,
+                                                       _stream()), "fft_exec_r2c_spectrum_s16x2")
         return out
 
     def c2r(self, x, out=None):
@@ -282,6 +316,21 @@ class ToneGen:
         _check(lib().dspmi_tonegen_f32(out.data_ptr(), out.stride(0) if self.nchan > 1 else n, n, self.nchan, self.ntone,
                                        self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
                                        int(self.use_sin), wp, wb, _stream()), "tonegen")
+        return out
+
+    def read_s16x2(self, n, sequential=False):
+        """Next n samples of every channel as stereo int16 frames [nchan, n, 2] (both channels equal)."""
+        import torch
+        out = torch.empty((self.nchan, n, 2), dtype=torch.int16, device=self.w.device)
+        wp, wb = None, 0
+        if not sequential:
+            wb = lib().dspmi_tonegen_work_bytes(n, self.nchan, self.ntone)
+            if getattr(self, "_work", None) is None or self._work.numel() < wb:
+                self._work = torch.empty(wb, dtype=torch.uint8, device=self.w.device)
+            wp = self._work.data_ptr()
+        _check(lib().dspmi_tonegen_s16x2(out.data_ptr(), n, n, self.nchan, self.ntone,
+                                         self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
+                                         int(self.use_sin), wp, wb, _stream()), "tonegen_s16x2")
         return out
 
 

@@ -26,6 +26,7 @@
 #define DSPMI_H_INCLUDED
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -91,6 +92,17 @@ int dspmi_fir_exec_f64(dspmi_fir_t plan, double *y, size_t y_stride, unsigned nx
                        const double *x, size_t x_stride, unsigned nx,
                        unsigned nchan, const double *hist, size_t hist_stride,
                        unsigned flags, void *stream);
+
+/* Capture blocks of interleaved 16-bit stereo frames through the FIR stage, the whole of
+ * do_fir (alsa/main.c:518-540) per block: a frame enters as ((double)left + (double)right) / 2,
+ * the block is convolved from zero initial state (no history is carried between blocks,
+ * alsa/main.c:530), and result i < nsampl leaves as (int16_t)value in both channels.
+ * in/out: device, [nblock] blocks of nsampl frames, strides in frames (4 bytes each); they
+ * must not overlap.  plan: a double-precision plan -- products and sums are rounded one by one
+ * in the reference's order, so the 16-bit results are the reference's exactly.  A value outside
+ * the 32-bit range converts to 0, as the cast does in an x86 build of the reference. */
+int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, const int16_t *in,
+                         size_t in_stride, unsigned nsampl, unsigned nblock, void *stream);
 
 /* Name of the kernel variant the plan dispatches to (for profiles / logs). */
 const char *dspmi_fir_variant(dspmi_fir_t plan);
@@ -181,6 +193,12 @@ int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigne
 int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, size_t batch,
                                 unsigned nbin, int mode, float scale, void *stream);
 
+/* The same from capture blocks of interleaved 16-bit stereo frames, the whole of
+ * do_power_spectrum (alsa/main.c:453-492) per block with nbin = n/2 and DSPMI_PS_NORM: in
+ * [batch][n] frames (8-byte aligned), each entering as (left + right) / 2. */
+int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float *ps, size_t batch,
+                                      unsigned nbin, int mode, float scale, void *stream);
+
 /* Tone generator of tonegen/tonegen.c:25-40 on the device, one generator per channel:
  * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from
@@ -194,6 +212,13 @@ size_t dspmi_tonegen_work_bytes(unsigned n, unsigned nchan, unsigned ntone);
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
                       double *w, const double *dw, const double *amp, const double *phi,
                       int use_sin, void *work, size_t work_bytes, void *stream);
+/* Same generator, samples stored as interleaved 16-bit stereo frames: (int16_t)value in both
+ * channels (convert_double_to_s16x2, tonegen/main.c:14-24).  x_stride in frames.  The sum is
+ * formed in double as above; its cosines may differ from the host libm's in the last bit, so a
+ * sample whose exact value lies within ~1e-12 of an integer can come out one step apart. */
+int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
+                        double *w, const double *dw, const double *amp, const double *phi,
+                        int use_sin, void *work, size_t work_bytes, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Host drop-in wrappers (reference signatures; host double buffers)         */

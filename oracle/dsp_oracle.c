@@ -504,6 +504,46 @@ void oracle_mono_to_s16x2(short *buf, const double *mono, unsigned nsampl)
     }
 }
 
+/* One capture block through the FIR stage: stereo s16 -> mono double ->
+ * convolve over nsampl+nh outputs with zero initial state -> the first
+ * nsampl results cast to s16 into both channels.  `out` may alias `in`.
+ * Follows do_fir, alsa/main.c:518-540. */
+void oracle_alsa_do_fir(short *out, const short *in, unsigned nsampl,
+                        const double *h, unsigned nh)
+{
+    double *mono = (double *)malloc((size_t)nsampl * sizeof *mono);
+    double *y = (double *)malloc(((size_t)nsampl + nh) * sizeof *y);
+    oracle_s16x2_to_mono(mono, in, nsampl);
+    oracle_convolve(y, nsampl + nh, mono, nsampl, h, nh);
+    oracle_mono_to_s16x2(out, y, nsampl);
+    free(mono);
+    free(y);
+}
+
+/* One capture block through the spectrum stage: stereo s16 -> complex
+ * (mono, 0) -> forward DFT of nsampl points -> |X| over nsampl/2 bins
+ * divided by their sum.  Follows do_power_spectrum, alsa/main.c:453-492. */
+void oracle_alsa_do_power_spectrum(double *ps, const short *in, unsigned nsampl)
+{
+    double *z = (double *)malloc((size_t)nsampl * 2 * sizeof *z);
+    double *zz = (double *)malloc((size_t)nsampl * 2 * sizeof *zz);
+    unsigned i;
+    for (i = 0; i != nsampl; i++) {
+        z[2 * i] = ((double)in[2 * i] + (double)in[2 * i + 1]) / 2;
+        z[2 * i + 1] = 0;
+    }
+    oracle_dft(z, nsampl, zz, -1);
+    oracle_alsa_power_spectrum(ps, zz, nsampl / 2);
+    free(z);
+    free(zz);
+}
+
+/* Generated samples -> stereo s16, the cast of tonegen/main.c:14-24. */
+void oracle_double_to_s16x2(short *raw, const double *gen, unsigned n)
+{
+    oracle_mono_to_s16x2(raw, gen, n);
+}
+
 /* ------------------------------------------------------------------ */
 /* CPU-baseline timing loops (bench.py cpu_baseline leg)                */
 /* ------------------------------------------------------------------ */

@@ -59,6 +59,10 @@ def lib(variant=""):
         L.oracle_fft_batch.argtypes = [_dp, _dp, _u, _u, C.c_int, C.c_int]
         L.oracle_convolve_batch.argtypes = [_dp, _u, _dp, _u, _dp, _u, _u]
         L.oracle_sin_tonegen_read.argtypes = [_dp, _dp, _u, _dp, _u]
+        _sp = C.POINTER(C.c_short)
+        L.oracle_alsa_do_fir.argtypes = [_sp, _sp, _u, _dp, _u]
+        L.oracle_alsa_do_power_spectrum.argtypes = [_dp, _sp, _u]
+        L.oracle_double_to_s16x2.argtypes = [_sp, _dp, _u]
         for f in ("oracle_conv0", "oracle_conv1", "oracle_convolve",
                   "oracle_fir_batch_f32", "oracle_fir_stream_f32",
                   "oracle_dft_direct", "oracle_fft_radix2", "oracle_dft",
@@ -66,7 +70,8 @@ def lib(variant=""):
                   "oracle_power_spectrum", "oracle_ps_abs", "oracle_ps_percent",
                   "oracle_compute_phi", "oracle_alsa_power_spectrum",
                   "oracle_fft_batch", "oracle_convolve_batch",
-                  "oracle_sin_tonegen_read"):
+                  "oracle_sin_tonegen_read", "oracle_alsa_do_fir",
+                  "oracle_alsa_do_power_spectrum", "oracle_double_to_s16x2"):
             getattr(L, f).restype = None
         _libs[variant] = L
     return _libs[variant]
@@ -230,6 +235,35 @@ def alsa_power_spectrum(z):
     z, zp = _c2d(z)
     nb = len(z) // 2
     out = np.empty(nb); lib().oracle_alsa_power_spectrum(out.ctypes.data_as(_dp), zp, nb)
+    return out
+
+
+_sp = C.POINTER(C.c_short)
+
+
+def alsa_do_fir(frames, h):
+    """alsa/main.c:518-540 on one block of interleaved stereo s16 frames [nsampl, 2]."""
+    frames = np.ascontiguousarray(frames, dtype=np.int16)
+    h = np.ascontiguousarray(h, dtype=np.float64)
+    out = np.empty_like(frames)
+    lib().oracle_alsa_do_fir(out.ctypes.data_as(_sp), frames.ctypes.data_as(_sp), frames.shape[0],
+                             h.ctypes.data_as(_dp), len(h))
+    return out
+
+
+def alsa_do_power_spectrum(frames):
+    """alsa/main.c:453-492 on one block of interleaved stereo s16 frames [nsampl, 2]."""
+    frames = np.ascontiguousarray(frames, dtype=np.int16)
+    out = np.empty(frames.shape[0] // 2)
+    lib().oracle_alsa_do_power_spectrum(out.ctypes.data_as(_dp), frames.ctypes.data_as(_sp), frames.shape[0])
+    return out
+
+
+def double_to_s16x2(gen):
+    """tonegen/main.c:14-24."""
+    gen = np.ascontiguousarray(gen, dtype=np.float64)
+    out = np.empty((len(gen), 2), dtype=np.int16)
+    lib().oracle_double_to_s16x2(out.ctypes.data_as(_sp), gen.ctypes.data_as(_dp), len(gen))
     return out
 
 

@@ -143,3 +143,22 @@ def test_tonegen_recurrence():
         w1 += (2.0 * np.pi * 1000.0) / 48000.0
         w2 += (2.0 * np.pi * 3000.0) / 48000.0
     np.testing.assert_allclose(np.concatenate([a, b]), ref, rtol=0, atol=1e-12)
+
+
+def test_capture_block_stages_compose_from_their_parts():
+    """alsa/main.c:453-540 restated as whole-block functions equal the step-by-step composition."""
+    rng = np.random.default_rng(11)
+    fr = rng.integers(-32768, 32768, size=(2048, 2)).astype(np.int16)
+    mono = (fr[:, 0].astype(np.float64) + fr[:, 1].astype(np.float64)) / 2
+    y = oracle.convolve(mono, oracle.TAPS16, 2048 + 16)[:2048]
+    out = oracle.alsa_do_fir(fr, oracle.TAPS16)
+    assert np.array_equal(out[:, 0], np.trunc(y).astype(np.int64).astype(np.int16))
+    assert np.array_equal(out[:, 0], out[:, 1])
+    ps = oracle.alsa_do_power_spectrum(fr)
+    z = np.fft.fft(mono)[:1024]
+    assert np.allclose(ps, np.abs(z) / np.abs(z).sum(), rtol=1e-9, atol=1e-15)
+    # tonegen/main.c "10 2000,400,0" at 44.1 kHz: the stream starts 400,400,383,383,336,336
+    t = oracle.Tonegen()
+    t.add(44100.0, 2000.0, 400.0, 0.0)
+    raw = oracle.double_to_s16x2(t.read(5))
+    assert raw.reshape(-1)[:6].tolist() == [400, 400, 383, 383, 336, 336]
