@@ -10,6 +10,6 @@ from .lib import (  # noqa: F401
     DspmiError, FirPlan, FftPlan, OlsPlan, ToneGen, power_spectrum, lib, lib_path,
     PS_NORM_GUARDED, PS_NORM, PS_ABS,
     conv0, conv1, convolve, convolve_alloc, fir, fir_set_taps,
-    dft, idft, fft_r2c, fft_mag, filter,
+    dft, idft, fft_r2c, fft_mag, filter, make_blackman_window, make_filter_kernel,
     FORWARD, BACKWARD, F32, F64, FIR_DROP_FIRST,
 )

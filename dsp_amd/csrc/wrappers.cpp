@@ -7,6 +7,7 @@
 // routines return void in the reference, and there is no CPU fallback.
 #include "common.h"
 
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -154,6 +155,35 @@ void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx)
     DSPMI_OR_DIE(dspmi::ps_abs_f64(dout.p, dmag.as<double>(), nx / 2, (double)nx, 1, nx, nullptr));
     DSPMI_HIP_OR_DIE(hipMemcpy(xx, dmag.p, (size_t)(nx / 2) * sizeof(double), hipMemcpyDeviceToHost));
     DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+}
+
+void dsp_make_blackman_window(double *x, unsigned int nx)
+{
+    // the denominator is nx, not nx - 1 (fir/src/main.c:143-144)
+    for (unsigned i = 0; i < nx; i++)
+        x[i] = 0.42 - 0.5 * cos((2.0 * M_PI * (double)i) / (double)nx) + 0.08 * cos((4 * M_PI * (double)i) / (double)nx);
+}
+
+void dsp_make_filter_kernel(const double *fresp, unsigned int nx, double (*kernel)[2])
+{
+    if (nx == 0) return;
+    const unsigned n2 = 2 * nx;
+    // spectrum: the response halved, then its mirror image (fir/src/main.c:166-179)
+    std::vector<double> spec((size_t)n2 * 2, 0.0), imp((size_t)n2 * 2);
+    for (unsigned i = 0; i < nx; i++) spec[2 * i] = fresp[i] / 2;
+    for (unsigned i = 0; i < nx; i++) spec[2 * (nx + i)] = spec[2 * (nx - 1 - i)];
+    run_c2c(reinterpret_cast<double(*)[2]>(spec.data()), n2, reinterpret_cast<double(*)[2]>(imp.data()), DSPMI_BACKWARD);
+    // the first nk/2 impulse-response samples, mirrored about the centre of an nk-tap kernel
+    const unsigned nk = n2 < 32 ? n2 : 32, half = nk / 2;
+    for (unsigned i = 0; i < half; i++)
+        for (int c = 0; c < 2; c++) kernel[half - 1 - i][c] = kernel[half + i][c] = imp[2 * i + c];
+    for (unsigned i = nk; i < n2; i++) kernel[i][0] = kernel[i][1] = 0.0;
+    std::vector<double> w(nk);
+    dsp_make_blackman_window(w.data(), nk);
+    for (unsigned i = 0; i < nk; i++) {
+        kernel[i][0] *= w[i];
+        kernel[i][1] *= w[i];
+    }
 }
 
 void dsp_filter(double *xx, const double *x, unsigned int n, const double *coeffs)

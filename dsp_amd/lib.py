@@ -73,6 +73,8 @@ _SIGS = {
     "dsp_fft_r2c": (None, [_dp, _dp, _u]),
     "dsp_fft_mag": (None, [_dp, _u, _dp]),
     "dsp_filter": (None, [_dp, _dp, _u, _dp]),
+    "dsp_make_blackman_window": (None, [_dp, _u]),
+    "dsp_make_filter_kernel": (None, [_dp, _u, _dp]),
 }
 
 
@@ -482,3 +484,18 @@ def filter(x, coeffs):  # noqa: A001 - the reference's name
     xx = np.empty(len(x))
     lib().dsp_filter(xx.ctypes.data_as(_dp), xp, len(x), cp)
     return xx
+
+
+def make_blackman_window(nx):
+    """fir/src/main.c:138-146."""
+    w = np.empty(nx)
+    lib().dsp_make_blackman_window(w.ctypes.data_as(_dp), nx)
+    return w
+
+
+def make_filter_kernel(fresp):
+    """fir/src/main.c:149-226 -- complex kernel of 2*len(fresp) values (at most 32 non-zero)."""
+    f, fp = _d(fresp)
+    k = np.empty(2 * len(f), dtype=np.complex128)
+    lib().dsp_make_filter_kernel(fp, len(f), k.view(np.float64).ctypes.data_as(_dp))
+    return k

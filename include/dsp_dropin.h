@@ -62,6 +62,13 @@ static inline void fft(fftw_complex *x, unsigned int nx, double *xx) { dsp_fft_m
 static inline void fft(double *xx, const double *x, unsigned int n) { dsp_fft_r2c(xx, x, n); }
 #endif
 
+/* fir/src/main.c:138-226 */
+static inline void make_blackman_window(double *x, unsigned int nx) { dsp_make_blackman_window(x, nx); }
+static inline void make_filter_kernel(const double *fresp, unsigned int nx, fftw_complex *kernel)
+{
+    dsp_make_filter_kernel(fresp, nx, kernel);
+}
+
 /* util/filter/filter.c:73-105 */
 static inline void filter(double *xx, const double *x, unsigned int n, const double *coeffs)
 {

@@ -248,6 +248,15 @@ void dsp_idft(double (*in)[2], unsigned int nx, double (*out)[2]);
 void dsp_fft_r2c(double *xx, const double *x, unsigned int n);
 /* fir/src/main.c:229-255: xx[i] = 2|X[i]|/nx for i < nx/2 */
 void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx);
+/* make_blackman_window (fir/src/main.c:138-146): 0.42 - 0.5 cos(2 pi i/nx) + 0.08 cos(4 pi i/nx). */
+void dsp_make_blackman_window(double *x, unsigned int nx);
+
+/* make_filter_kernel (fir/src/main.c:149-226): filter kernel from a magnitude response.
+ * fresp[nx] -> unnormalised backward DFT of the 2*nx-point mirrored spectrum fresp/2 -> the
+ * first min(2*nx, 32)/2 samples mirrored into a min(2*nx, 32)-tap kernel, Blackman-windowed,
+ * the remaining kernel[.. 2*nx) zeroed.  kernel: 2*nx complex values, caller-owned. */
+void dsp_make_filter_kernel(const double *fresp, unsigned int nx, double (*kernel)[2]);
+
 /* util/filter/filter.c:73-105 */
 void dsp_filter(double *xx, const double *x, unsigned int n, const double *coeffs);
 

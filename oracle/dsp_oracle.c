@@ -545,6 +545,72 @@ void oracle_double_to_s16x2(short *raw, const double *gen, unsigned n)
 }
 
 /* ------------------------------------------------------------------ */
+/* Filter-kernel designer (fir/src/main.c:108-226)                      */
+/* ------------------------------------------------------------------ */
+
+/* Pass bands alternate at every cut frequency, starting in a stop band.
+ * Follows make_multipass_fresp, fir/src/main.c:108-135. */
+void oracle_make_multipass_fresp(double *x, unsigned nx, const double *fcuts,
+                                 unsigned ncuts, double fsampl)
+{
+    const double fband = fsampl / (((double)nx - 1) * 2);
+    double level = -1;
+    unsigned i, j = 0;
+    for (i = 0; i != nx; i++) {
+        if (j < ncuts && (double)i * fband >= fcuts[j]) {
+            level *= -1;
+            j++;
+        }
+        x[i] = (1 + level) / 2;
+    }
+}
+
+/* Follows make_blackman_window, fir/src/main.c:138-146 (denominator nx). */
+void oracle_make_blackman_window(double *x, unsigned nx)
+{
+    unsigned i;
+    for (i = 0; i != nx; i++)
+        x[i] = 0.42 - 0.5 * cos((2.0 * M_PI * (double)i) / (double)nx)
+             + 0.08 * cos((4 * M_PI * (double)i) / (double)nx);
+}
+
+/* Follows make_filter_kernel, fir/src/main.c:149-226: backward DFT of the
+ * mirrored half response, first nk/2 samples mirrored into nk taps, window. */
+void oracle_make_filter_kernel(const double *fresp, unsigned nx, double *kernel)
+{
+    const unsigned nxx = nx * 2;
+    const unsigned nk = nxx < 32 ? nxx : 32;
+    const unsigned nkk = nk / 2;
+    double *in = (double *)calloc((size_t)nxx * 2, sizeof *in);
+    double *out = (double *)malloc((size_t)nxx * 2 * sizeof *out);
+    double *w = (double *)malloc((size_t)nk * sizeof *w);
+    unsigned i;
+    for (i = 0; i != nx; i++)
+        in[2 * i] = fresp[i] / 2;
+    for (i = 0; i != nx; i++) {
+        in[2 * (nx + i)] = in[2 * (nx - i - 1)];
+        in[2 * (nx + i) + 1] = in[2 * (nx - i - 1) + 1];
+    }
+    oracle_dft(in, nxx, out, +1);
+    for (i = 0; i != nkk; i++) {
+        kernel[2 * (nkk - i - 1)] = out[2 * i];
+        kernel[2 * (nkk - i - 1) + 1] = out[2 * i + 1];
+        kernel[2 * (nkk + i)] = out[2 * i];
+        kernel[2 * (nkk + i) + 1] = out[2 * i + 1];
+    }
+    for (i = nk; i != nxx; i++)
+        kernel[2 * i] = kernel[2 * i + 1] = 0;
+    oracle_make_blackman_window(w, nk);
+    for (i = 0; i != nk; i++) {
+        kernel[2 * i] *= w[i];
+        kernel[2 * i + 1] *= w[i];
+    }
+    free(in);
+    free(out);
+    free(w);
+}
+
+/* ------------------------------------------------------------------ */
 /* CPU-baseline timing loops (bench.py cpu_baseline leg)                */
 /* ------------------------------------------------------------------ */
 

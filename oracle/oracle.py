@@ -63,6 +63,9 @@ def lib(variant=""):
         L.oracle_alsa_do_fir.argtypes = [_sp, _sp, _u, _dp, _u]
         L.oracle_alsa_do_power_spectrum.argtypes = [_dp, _sp, _u]
         L.oracle_double_to_s16x2.argtypes = [_sp, _dp, _u]
+        L.oracle_make_multipass_fresp.argtypes = [_dp, _u, _dp, _u, C.c_double]
+        L.oracle_make_blackman_window.argtypes = [_dp, _u]
+        L.oracle_make_filter_kernel.argtypes = [_dp, _u, _dp]
         for f in ("oracle_conv0", "oracle_conv1", "oracle_convolve",
                   "oracle_fir_batch_f32", "oracle_fir_stream_f32",
                   "oracle_dft_direct", "oracle_fft_radix2", "oracle_dft",
@@ -71,7 +74,9 @@ def lib(variant=""):
                   "oracle_compute_phi", "oracle_alsa_power_spectrum",
                   "oracle_fft_batch", "oracle_convolve_batch",
                   "oracle_sin_tonegen_read", "oracle_alsa_do_fir",
-                  "oracle_alsa_do_power_spectrum", "oracle_double_to_s16x2"):
+                  "oracle_alsa_do_power_spectrum", "oracle_double_to_s16x2",
+                  "oracle_make_multipass_fresp", "oracle_make_blackman_window",
+                  "oracle_make_filter_kernel"):
             getattr(L, f).restype = None
         _libs[variant] = L
     return _libs[variant]
@@ -265,6 +270,29 @@ def double_to_s16x2(gen):
     out = np.empty((len(gen), 2), dtype=np.int16)
     lib().oracle_double_to_s16x2(out.ctypes.data_as(_sp), gen.ctypes.data_as(_dp), len(gen))
     return out
+
+
+def make_multipass_fresp(nx, fcuts, fsampl):
+    """fir/src/main.c:108-135."""
+    fc = np.ascontiguousarray(fcuts, dtype=np.float64)
+    x = np.empty(nx)
+    lib().oracle_make_multipass_fresp(x.ctypes.data_as(_dp), nx, fc.ctypes.data_as(_dp), len(fc), fsampl)
+    return x
+
+
+def make_blackman_window(nx):
+    """fir/src/main.c:138-146."""
+    x = np.empty(nx)
+    lib().oracle_make_blackman_window(x.ctypes.data_as(_dp), nx)
+    return x
+
+
+def make_filter_kernel(fresp):
+    """fir/src/main.c:149-226."""
+    f = np.ascontiguousarray(fresp, dtype=np.float64)
+    k = np.empty(2 * len(f), dtype=np.complex128)
+    lib().oracle_make_filter_kernel(f.ctypes.data_as(_dp), len(f), k.view(np.float64).ctypes.data_as(_dp))
+    return k
 
 
 # ---- tone generator ---------------------------------------------------------

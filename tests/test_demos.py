@@ -20,7 +20,7 @@ def _build():
 
 def test_demos_compile_as_plain_c():
     _build()
-    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo"):
+    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo", "firdesign_demo"):
         assert os.path.exists(os.path.join(BIN, name))
 
 
@@ -95,3 +95,35 @@ def test_fftw_subset_demo_matches_oracle():
     g = np.where(np.arange(2049) * 48000.0 / 4096 < 3000, 1.0, 0.0)
     assert filt.shape == (4096, 3)
     np.testing.assert_allclose(filt[:, 2], oracle.filter(s, g), atol=1e-6)
+
+
+CUTS = [1000, 2500, 3000, 3200, 6000, 10000, 14000, 20000]
+
+
+@pytest.mark.gpu
+def test_filter_kernel_designer_matches_oracle():
+    """make_filter_kernel (fir/src/main.c:149-226) over the device backward DFT (482 points:
+    not a power of two) against the oracle's long-double DFT."""
+    import dsp_amd
+    for nx, cuts in ((241, CUTS), (8, [6000]), (16, [3000, 9000]), (1025, CUTS)):
+        fresp = oracle.make_multipass_fresp(nx, cuts, 48000.0)
+        want = oracle.make_filter_kernel(fresp)
+        got = dsp_amd.make_filter_kernel(fresp)
+        assert got.shape == want.shape == (2 * nx,)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+        assert not got[32:].any()
+    assert np.array_equal(dsp_amd.make_blackman_window(32), oracle.make_blackman_window(32))
+
+
+@pytest.mark.gpu
+def test_firdesign_demo_matches_oracle():
+    fresp = oracle.make_multipass_fresp(241, CUTS, 48000.0)
+    kern = oracle.make_filter_kernel(fresp)
+    achieved = oracle.ps_abs(oracle.dft(kern, -1, "direct"))
+    rows = np.array([[float(v) for v in ln.split()] for ln in _run("firdesign_demo").splitlines()])
+    assert rows.shape == (241, 5)
+    np.testing.assert_allclose(rows[:, 0], 100.0 * np.arange(241), atol=1e-6)
+    assert np.array_equal(rows[:, 1], fresp)
+    np.testing.assert_allclose(rows[:, 2], kern.real[:241], atol=1e-6)
+    np.testing.assert_allclose(rows[:, 3], kern.imag[:241], atol=1e-6)
+    np.testing.assert_allclose(rows[:, 4], achieved[:241], atol=1e-6)
