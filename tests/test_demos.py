@@ -20,7 +20,7 @@ def _build():
 
 def test_demos_compile_as_plain_c():
     _build()
-    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo", "firdesign_demo"):
+    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo", "firdesign_demo", "fft_tool", "filter_tool"):
         assert os.path.exists(os.path.join(BIN, name))
 
 
@@ -127,3 +127,74 @@ def test_firdesign_demo_matches_oracle():
     np.testing.assert_allclose(rows[:, 2], kern.real[:241], atol=1e-6)
     np.testing.assert_allclose(rows[:, 3], kern.imag[:241], atol=1e-6)
     np.testing.assert_allclose(rows[:, 4], achieved[:241], atol=1e-6)
+
+
+def _table(tmp_path, cols):
+    """A text table in the tools' format (util/common/csv.c): comment and blank lines ignored."""
+    path = os.path.join(str(tmp_path), "table.txt")
+    with open(path, "w") as f:
+        f.write("# t x\n\n")
+        for i, row in enumerate(zip(*cols)):
+            f.write(" ".join("%.17g" % v for v in row) + "\n")
+            if i == 3:
+                f.write("# a comment in the middle\n\n")
+    return path
+
+
+def _tool(name, *args):
+    _build()
+    return subprocess.run([os.path.join(BIN, name)] + list(args), capture_output=True, text=True, timeout=120)
+
+
+def test_tools_reject_bad_command_lines(tmp_path):
+    """Argument and window checks happen before any device work (util/fft/fft.c:262-326)."""
+    t = np.arange(100) / 1000.0
+    path = _table(tmp_path, [t, np.sin(t)])
+    for tool in ("fft_tool", "filter_tool"):
+        assert _tool(tool, "-ifile").returncode == 255                                   # odd count
+        assert _tool(tool, "-bogus", "1").returncode == 255
+        assert _tool(tool, "-icol", "1", "-fsampl", "1000").returncode == 255            # no -ifile
+        assert _tool(tool, "-ifile", path, "-fsampl", "1000").returncode == 255          # no -icol
+        assert _tool(tool, "-ifile", path + ".missing", "-icol", "1", "-fsampl", "1000").returncode == 255
+        # the default window end is fsampl * rows seconds: longer than any table
+        assert _tool(tool, "-ifile", path, "-icol", "1", "-fsampl", "1000").returncode == 255
+    assert _tool("fft_tool", "-ifile", path, "-icol", "1", "-fsampl", "1000", "-tsampl_lo", "0.2",
+                 "-tsampl_hi", "0.3").returncode == 255                                   # starts past the end
+
+
+@pytest.mark.gpu
+def test_fft_tool_matches_oracle(tmp_path):
+    fs = 48000.0
+    tg = oracle.Tonegen()
+    tg.add(fs, 1000.0, 1.0, 0.0); tg.add(fs, 12000.0, 0.5, 0.3)
+    x = tg.read(1200)
+    path = _table(tmp_path, [np.arange(1200) / fs, x])
+    r = _tool("fft_tool", "-ifile", path, "-icol", "0x1", "-fsampl", "48000", "-tsampl_lo", "0.005", "-tsampl_hi", "0.015")
+    assert r.returncode == 0, r.stderr
+    rows = np.array([[float(v) for v in ln.split()] for ln in r.stdout.splitlines()])
+    n = 480                                                    # ceil(0.01 * 48000): not a power of two
+    assert rows.shape == (n // 2 + 1, 2)
+    np.testing.assert_allclose(rows[:, 0], np.arange(n // 2 + 1) * fs / n, atol=1e-6)
+    want = oracle.power_spectrum(oracle.fft_r2c(x[240:240 + n]))
+    np.testing.assert_allclose(rows[:, 1], want, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_filter_tool_matches_oracle(tmp_path):
+    fs = 48000.0
+    tg = oracle.Tonegen()
+    tg.add(fs, 1000.0, 1.0, 0.0); tg.add(fs, 12000.0, 0.5, 0.3)
+    x = tg.read(5000)
+    path = _table(tmp_path, [np.arange(5000) / fs, x])
+    r = _tool("filter_tool", "-ifile", path, "-icol", "1", "-fsampl", "48000", "-tsampl", "0.01:0.0953333:",
+              "-filter", "3000:24000:0:", "-filter", "3000:3500:0.5:")
+    assert r.returncode == 0, r.stderr
+    rows = np.array([[float(v) for v in ln.split()] for ln in r.stdout.splitlines()])
+    first, n = 480, int(np.ceil((0.0953333 - 0.01) * fs))
+    assert rows.shape == (n, 3)
+    fband = fs / n
+    gains = np.ones(n // 2 + 1)
+    for lo, hi, g in ((3000.0, 3500.0, 0.5), (3000.0, 24000.0, 0.0)):      # last given, first applied
+        gains[int(np.floor(lo / fband)):min(int(np.ceil(hi / fband)), len(gains))] = g
+    np.testing.assert_allclose(rows[:, 1], x[first:first + n], atol=6e-7)
+    np.testing.assert_allclose(rows[:, 2], oracle.filter(x[first:first + n], gains), atol=6e-7)
