@@ -41,6 +41,7 @@ struct FirParams {
     unsigned tiles_per_chan;
     unsigned flags;
     unsigned ntiles_total, tiles_per_block;  // MFMA kernel: tiles over all channels / per workgroup
+    int prio_mode;                           // MFMA kernel: wave-priority policy (see set_prio)
 };
 
 template <typename T> struct Vec4;
@@ -237,9 +238,21 @@ constexpr unsigned mfma_lds_floats(unsigned tile, unsigned seglen)
 // input window of unit u+1 is already on its way from HBM into registers, and
 // is written to LDS once the loop is done (one LDS buffer, two barriers).
 // NIT = staging registers per lane = ceil((tile + segment - 1) / 256).
+__device__ __forceinline__ void set_prio(int level)
+{
+    switch (level & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 template <int NIT, int TPW>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 {
+    if (p.prio_mode == 1) set_prio(blockIdx.x);
+    if (p.prio_mode == 3) set_prio(blockIdx.x >> 8);
     constexpr int kMfmaTile = mfma_tile(TPW);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *lds = reinterpret_cast<float *>(smem_raw);
@@ -339,7 +352,12 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
     // registers -> LDS, plus the segment's reversed tap table when it changes
     auto commit = [&](const Unit &d, bool first) {
         const unsigned l0 = xpad(t);  // xpad(t + 256*it) = xpad(t) + 16*kRow*it
-        if (d.plain) {
+        if (d.plain && d.nstage >= 256 * (NIT - 1)) {
+            // every staging round but the last is full
+#pragma unroll
+            for (int it = 0; it < NIT - 1; it++) xs[l0 + 16 * kRow * it] = stage[it];
+            if ((int)(t + 256 * (NIT - 1)) < d.nstage) xs[l0 + 16 * kRow * (NIT - 1)] = stage[NIT - 1];
+        } else if (d.plain) {
 #pragma unroll
             for (int it = 0; it < NIT; it++)
                 if ((int)(t + 256 * it) < d.nstage) xs[l0 + 16 * kRow * it] = stage[it];
@@ -382,28 +400,47 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 
         const int seglen = cur.seglen;  // multiple of 16
         const bool last_seg = cur.seg0 + cur.seglen >= (int)p.nhp;
-        if (cur.seg0 == 0) {
-#pragma unroll
-            for (int q = 0; q < TPW; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
 
+        if (p.prio_mode == 2) set_prio(3);
+        if (p.prio_mode == 4) set_prio(blockIdx.x + (int)unit);
         const float *ap = hr + a_base;
         const float *bp = xs + b_base;
-        const int nu = (seglen + 16) / 16;  // 16 window positions (4 MFMA steps) per iteration
-        for (int u = 0; u < nu; u++) {
+        // 16 window positions (4 MFMA steps per tile) per group; the vector ALU shares its
+        // pipe with the f32 MFMAs, so every address update costs MFMA issue slots: groups are
+        // unrolled three at a time, and a tile's first segment starts its accumulators from
+        // the instruction's constant-zero operand instead of clearing registers
+        auto group = [&](const float *a_ptr, const float *b_ptr, bool zero) {
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                const float a = ap[4 * v];
+                const float a = a_ptr[4 * v];
 #pragma unroll
                 for (int q = 0; q < TPW; q++) {
-                    const float b = bp[q * (256 / 16 * kRow) + 4 * v];
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+                    const float b = b_ptr[q * (256 / 16 * kRow) + 4 * v];
+                    const f32x4 c = (zero && v == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[q];
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
                 }
             }
+        };
+        int nu = (seglen + 16) / 16;  // >= 2
+        if (cur.seg0 == 0) group(ap, bp, true);
+        else group(ap, bp, false);
+        ap += 16;
+        bp += kRow;
+        nu--;
+        for (; nu >= 3; nu -= 3) {
+            group(ap, bp, false);
+            group(ap + 16, bp + kRow, false);
+            group(ap + 32, bp + 2 * kRow, false);
+            ap += 48;
+            bp += 3 * kRow;
+        }
+        for (; nu > 0; nu--) {
+            group(ap, bp, false);
             ap += 16;
             bp += kRow;
         }
 
+        if (p.prio_mode == 2) set_prio(0);
         if (last_seg) {
             // D layout: column n = lane&15, rows 4*(lane>>4) .. +3 -> 4 consecutive outputs per
             // lane; the wave's 64 lanes cover 1 KiB contiguously.
@@ -476,6 +513,10 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
         const int bpc = env && atoi(env) > 0 ? atoi(env) : bpc_default;
         const size_t want = (160 * 1024) / bpc - 512;
         if (want > lds) lds = want;
+    }
+    {
+        const char *env = getenv("DSPMI_FIR_PRIO");
+        p.prio_mode = env ? atoi(env) : 0;
     }
     p.tiles_per_chan = (p.nxx + TILE - 1) / TILE;
     const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
@@ -576,7 +617,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     FirParams<T> p;
     p.y = y; p.x = x; p.hist = hist; p.taps = static_cast<const T *>(pl->taps_dev);
     p.y_stride = y_stride; p.x_stride = x_stride; p.hist_stride = hist_stride;
-    p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags;
+    p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags; p.prio_mode = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if constexpr (sizeof(T) == 4) {
         if (pl->variant == V_F32_MFMA) {
@@ -666,7 +707,7 @@ int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, cons
     p.y = reinterpret_cast<double *>(out); p.x = reinterpret_cast<const double *>(in); p.hist = nullptr;
     p.taps = static_cast<const double *>(plan->taps_dev);
     p.y_stride = out_stride; p.x_stride = in_stride; p.hist_stride = 0;
-    p.nxx = nsampl; p.nx = nsampl; p.nh = plan->nh; p.nhp = plan->nhp; p.flags = 0;
+    p.nxx = nsampl; p.nx = nsampl; p.nh = plan->nh; p.nhp = plan->nhp; p.flags = 0; p.prio_mode = 0;
     p.tiles_per_chan = (nsampl + 2047) / 2048;
     return launch<double, 4, 2, 8, true, false, true>(p, nblock, static_cast<hipStream_t>(stream));
 }

@@ -24,7 +24,8 @@ class DspmiError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdspmi.so")
+    # DSPMI_LIB: another build of the same library (A/B timing of two kernel versions on one box)
+    return os.environ.get("DSPMI_LIB") or os.path.join(_HERE, "libdspmi.so")
 
 
 _lib = None
