@@ -507,7 +507,7 @@ struct OlsArgs {
 // forward transform's last pass (j + r*N/R) are exactly the ones the backward transform's
 // first pass wants: the spectrum is multiplied in registers and goes straight back in.
 template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
-__global__ __launch_bounds__(block_threads<NT>()) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
+__global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_per_eu(3, 8))) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
 {
     typedef float T;
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
@@ -538,19 +538,35 @@ __global__ __launch_bounds__(block_threads<NT>()) void ols_fused_kernel(const Ol
         const float *hrow = a.hist ? a.hist + c * a.hist_stride : nullptr;
         const long base = (long)(2 * p) * L - (nh - 1);  // sample index of element 0 of the even block
         const bool second = 2 * p + 1 < a.nblk;
-        const bool interior = active && base >= 0 && base + L + N <= nx && second;
+        // the edge path synchronises, so the choice has to be the same for every lane that
+        // takes part in that synchronisation: the wave (frames within one wave) or the workgroup
+        const bool mine = active && base >= 0 && base + L + N <= nx && second;
+        bool interior;
+        if constexpr (NT > 64) interior = __syncthreads_and(mine);
+        else interior = __all(mine);
 
+        // element m = tl + NT*b + r*STEP of the pair: re = x[base + m], im = x[base + L + m].
+        // One per-lane pointer per block of the pair; every other address is a compile-time
+        // offset from it.
         C<T> v[P];
+        if (interior) {
+            const float *p0 = xrow + base + tl;
+            const float *p1 = p0 + L;
 #pragma unroll
-        for (int b = 0; b < P / R0; b++)
+            for (int b = 0; b < P / R0; b++)
 #pragma unroll
-            for (int r = 0; r < R0; r++) {
-                const long s = base + tl + NT * b + r * STEP;
+                for (int r = 0; r < R0; r++) {
+                    v[b * R0 + r].re = __builtin_nontemporal_load(p0 + (NT * b + r * STEP));
+                    v[b * R0 + r].im = __builtin_nontemporal_load(p1 + (NT * b + r * STEP));
+                }
+        } else {
+            // edge of the signal (or an idle frame): a plain checked loop fills the frame's LDS
+            // image, so the unrolled code above stays free of per-element conditions
+#pragma unroll 1
+            for (int m = tl; m < N; m += NT) {
+                const long s = base + m;
                 C<T> q = {0.f, 0.f};
-                if (interior) {
-                    q.re = __builtin_nontemporal_load(&xrow[s]);
-                    q.im = __builtin_nontemporal_load(&xrow[s + L]);
-                } else if (active) {
+                if (active) {
                     if (s >= 0) q.re = s < nx ? xrow[s] : 0.f;
                     else if (hrow && s >= 1 - nh) q.re = hrow[nh - 1 + s];
                     const long s2 = s + L;
@@ -559,32 +575,59 @@ __global__ __launch_bounds__(block_threads<NT>()) void ols_fused_kernel(const Ol
                         else if (hrow && s2 >= 1 - nh) q.im = hrow[nh - 1 + s2];
                     }
                 }
-                v[b * R0 + r] = q;
+                lds[pad(m)] = q;
             }
+            frame_sync<NT>();
+#pragma unroll
+            for (int b = 0; b < P / R0; b++)
+#pragma unroll
+                for (int r = 0; r < R0; r++) v[b * R0 + r] = lds[pad(tl + NT * b + r * STEP)];
+            frame_sync<NT>();
+        }
 
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
         // spectrum times H, conjugated for the backward transform (conj . forward . conj)
+        {
+            const C<T> *hp = a.H + tl;
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            const unsigned pos = tl + NT * (i / R0) + (i % R0) * STEP;
-            const C<T> hq = a.H[pos];
-            const C<T> m = cmul(v[i], hq);
-            v[i] = {m.re, -m.im};
+            for (int i = 0; i < P; i++) {
+                const C<T> hq = hp[NT * (i / R0) + (i % R0) * STEP];
+                const C<T> m = cmul(v[i], hq);
+                v[i] = {m.re, -m.im};
+            }
         }
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
 
-        if (active) {
-            float *yrow = a.y + c * a.y_stride;
+        // outputs j = m - (nh-1) >= 0 of each block of the pair
+        if (interior) {
+            float *q0 = a.y + c * a.y_stride + ((long)(2 * p) * L - (nh - 1)) + tl;
+            float *q1 = q0 + L;
+            const int skip = (int)nh - 1 - (int)tl;  // element offsets below this are overlap
 #pragma unroll
             for (int i = 0; i < P; i++) {
-                const long pos = tl + NT * (i / R0) + (i % R0) * STEP;
-                const long j = pos - (nh - 1);
-                if (j >= 0) {
-                    const long o0 = (long)(2 * p) * L + j;
-                    if (o0 < nx) __builtin_nontemporal_store(v[i].re, &yrow[o0]);
-                    if (second && o0 + L < nx) __builtin_nontemporal_store(-v[i].im, &yrow[o0 + L]);
+                const int off = NT * (i / R0) + (i % R0) * STEP;
+                if (off >= skip) {
+                    __builtin_nontemporal_store(v[i].re, q0 + off);
+                    __builtin_nontemporal_store(-v[i].im, q1 + off);
                 }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < P; i++) lds[pad(tl + NT * (i / R0) + (i % R0) * STEP)] = v[i];
+            frame_sync<NT>();
+            if (active) {
+                float *yrow = a.y + c * a.y_stride;
+#pragma unroll 1
+                for (int m = tl; m < N; m += NT) {
+                    const long j = m - (nh - 1);
+                    if (j < 0) continue;
+                    const C<T> q = lds[pad(m)];
+                    const long o0 = (long)(2 * p) * L + j;
+                    if (o0 < nx) yrow[o0] = q.re;
+                    if (second && o0 + L < nx) yrow[o0 + L] = -q.im;
+                }
+            }
+            frame_sync<NT>();
         }
     }
 }
@@ -671,6 +714,10 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
         }
     }
     size_t grid = (size_t)num_cu * per_cu;
+    {
+        const char *env = getenv("DSPMI_FFT_GRIDX");
+        if (env && atoi(env) > 0) grid *= atoi(env);
+    }
     if (grid > nfb) grid = nfb;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds_req, s, static_cast<const C<T> *>(in),
                        static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), batch, backward);

@@ -481,6 +481,11 @@ struct dspmi_fir_plan {
     void *taps_dev;
     int variant;  // index into the table below
     std::vector<double> taps_host;
+    // f32 plans with enough taps also hold an overlap-save plan: the same outputs through
+    // FFTs cost fewer flops than 2*nh per sample once nh passes ~100 (doc/notes:81-82)
+    dspmi_ols_t ols = nullptr;
+    unsigned ols_n = 0;
+    char name[48] = "";
 };
 
 namespace {
@@ -550,6 +555,7 @@ int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 }
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
+constexpr unsigned kOlsMinTaps = 96;  // below this the direct kernel is HBM-bound already
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
 template <typename T, int R, int G, int NHB, bool EXACT, bool DESC, bool PCM = false>
@@ -596,10 +602,22 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
     if (precision == DSPMI_F64) {
         pl->variant = V_F64_EXACT;
     } else {
-        const char *force = getenv("DSPMI_FIR_VARIANT");
+        const char *force = getenv("DSPMI_FIR_VARIANT");  // A/B knob: valu | mfma | (default: automatic)
         if (force && !strcmp(force, "valu")) pl->variant = nh <= 32 ? V_F32_SHORT : V_F32_LONG;
         else pl->variant = V_F32_MFMA;
+        if constexpr (sizeof(T) == 4) {
+            if (!force && nh >= kOlsMinTaps && nh <= 8192) {
+                // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
+                // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384
+                unsigned n = 1024;
+                while (n < 4 * nh && n < 16384) n <<= 1;
+                if (dspmi_ols_create_f32(&pl->ols, taps, nh, n, device) == DSPMI_OK) pl->ols_n = n;
+                else pl->ols = nullptr;
+            }
+        }
     }
+    if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
+    else snprintf(pl->name, sizeof pl->name, "%s", kVariantName[pl->variant]);
     *out = pl;
     return DSPMI_OK;
 }
@@ -620,6 +638,10 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags; p.prio_mode = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if constexpr (sizeof(T) == 4) {
+        // overlap-save covers the plain case: as many outputs as inputs, rows long enough to
+        // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
+        if (pl->ols && flags == 0 && nxx == nx && nx >= 2 * pl->ols_n)
+            return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
         if (pl->variant == V_F32_MFMA) {
             return launch_mfma(p, nchan, s);
         }
@@ -662,6 +684,7 @@ int dspmi_fir_create_f64(dspmi_fir_t *plan, const double *taps, unsigned nh, int
 int dspmi_fir_destroy(dspmi_fir_t plan)
 {
     if (!plan) return DSPMI_OK;
+    if (plan->ols) (void)dspmi_ols_destroy(plan->ols);
     hipError_t e = hipFree(plan->taps_dev);
     delete plan;
     if (e != hipSuccess) return dspmi::fail(DSPMI_EIO, "fir_destroy: %s", hipGetErrorString(e));
@@ -714,7 +737,7 @@ int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, cons
 
 const char *dspmi_fir_variant(dspmi_fir_t plan)
 {
-    return plan ? kVariantName[plan->variant] : "";
+    return plan ? plan->name : "";
 }
 
 }  // extern "C"

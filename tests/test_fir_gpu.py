@@ -82,9 +82,18 @@ def test_wrapper_long_kernel_multi_segment():
 
 # ---- f32 device API -----------------------------------------------------------------
 
+@pytest.fixture(params=["auto", "mfma"])
+def fir_path(request, monkeypatch):
+    """Plans pick overlap-save for long filters on long rows; "mfma" pins the direct kernel so
+    both are checked on the same cases."""
+    if request.param != "auto":
+        monkeypatch.setenv("DSPMI_FIR_VARIANT", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("nh", [1, 9, 16, 21, 32, 33, 127, 128, 300])
 @pytest.mark.parametrize("nx,nchan", [(1, 1), (100, 3), (4096, 2), (5000, 4), (70000, 2)])
-def test_f32_parity(nh, nx, nchan):
+def test_f32_parity(nh, nx, nchan, fir_path):
     rng = np.random.default_rng(nh * 1000 + nx)
     x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
     h = (oracle.windowed_sinc_taps(nh) if nh >= 9 else rng.uniform(-1, 1, nh)).astype(np.float32)
@@ -119,7 +128,7 @@ def test_f32_drop_first_is_conv1():
         assert rel_l2(got[c], ref) <= TOL_FIR
 
 
-def test_f32_streaming_history_matches_one_block():
+def test_f32_streaming_history_matches_one_block(fir_path):
     rng = np.random.default_rng(21)
     nchan, nh = 5, 127
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
@@ -138,7 +147,7 @@ def test_f32_streaming_history_matches_one_block():
         assert rel_l2(got[c], whole[c]) <= TOL_FIR
 
 
-def test_f32_strided_rows_and_unaligned_views():
+def test_f32_strided_rows_and_unaligned_views(fir_path):
     rng = np.random.default_rng(2)
     h = rng.uniform(-1, 1, 16).astype(np.float32)
     big = torch.from_numpy(rng.uniform(-1, 1, (4, 1000)).astype(np.float32)).cuda()
@@ -154,11 +163,12 @@ def test_f32_strided_rows_and_unaligned_views():
     assert torch.all(ybig[:, 0] == 0) and torch.all(ybig[:, 901:] == 0)  # nothing written outside the rows
 
 
-def test_linearity_and_impulse_at_scale():
+def test_linearity_and_impulse_at_scale(fir_path):
     """Size-independent properties on a block too large for the oracle to sweep."""
     nh, nchan, nx = 127, 64, 1 << 20
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     plan = dsp_amd.FirPlan(h, "f32")
+    assert ("overlap_save" in plan.variant) == (fir_path == "auto")
     g = torch.Generator(device="cuda").manual_seed(1)
     a = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
     b = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
@@ -169,8 +179,15 @@ def test_linearity_and_impulse_at_scale():
     imp[0, 0] = 1.0
     imp[1, nx - 200] = 1.0
     yi = plan.exec(imp).cpu().numpy()
-    assert np.array_equal(yi[0, :nh], h) and not yi[0, nh:].any()
-    assert np.array_equal(yi[1, nx - 200:nx - 200 + nh], h) and not yi[1, :nx - 200].any()
+    if fir_path == "mfma":
+        # one product per output, added to zeros: the taps come back exactly
+        assert np.array_equal(yi[0, :nh], h) and not yi[0, nh:].any()
+        assert np.array_equal(yi[1, nx - 200:nx - 200 + nh], h) and not yi[1, :nx - 200].any()
+    else:
+        # through the transforms: the taps to rounding, and rounding noise elsewhere
+        hn = np.linalg.norm(h)
+        assert rel_l2(yi[0, :nh], h) <= TOL_FIR and np.abs(yi[0, nh:]).max() <= 1e-6 * hn
+        assert rel_l2(yi[1, nx - 200:nx - 200 + nh], h) <= TOL_FIR and np.abs(yi[1, :nx - 200]).max() <= 1e-6 * hn
     # spot rows against the oracle
     want = oracle.fir_batch_f32(a[:2, :20000].cpu().numpy(), h, 20000)
     got = ya[:2, :20000].cpu().numpy()
@@ -179,7 +196,7 @@ def test_linearity_and_impulse_at_scale():
 
 
 @pytest.mark.parametrize("nh", [300, 127])
-def test_many_tiles_per_workgroup_walk(nh):
+def test_many_tiles_per_workgroup_walk(nh, fir_path):
     """Enough tiles that every workgroup walks several of them (the prefetch pipeline's steady
     state), with a tap count between the two staging-register variants; spot rows vs the oracle."""
     nchan, nx = 64, 1 << 21
