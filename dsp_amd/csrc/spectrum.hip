@@ -33,24 +33,41 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // sin / cos of a running angle.  The reference evaluates libm's sin/cos on the accumulated,
 // never-reduced angle (tonegen/tonegen.c:36-37; it reaches ~1e6 rad after a million samples),
-// where a generic device sin falls into its slow large-argument path on every lane.  The angle
-// is first brought to [-pi, pi] with a three-constant Cody-Waite reduction by 2*pi (exact to
-// ~1e-17 for |w| < 2^26 * 2*pi), then the library routine runs on the small argument.  The
-// value agrees with libm's to about an ulp of double, far below the f32 the sample is stored in.
-__device__ __forceinline__ double reduce_2pi(double w)
+// where a generic device sin falls into its slow large-argument path.  Here the angle is
+// reduced by multiples of pi/2 with a three-constant Cody-Waite step (each fused step leaves a
+// multiple of 2^-52 below 2, so it is exact; what remains is the ~1e-16 of the constants), and one
+// minimax polynomial in t^2 -- its coefficients chosen by the quadrant's parity -- gives
+// sin(t) or cos(t) on [-pi/4, pi/4].  The value agrees with libm's to about an ulp of double,
+// far below the f32 (or 16-bit) sample it ends up in.
+template <bool COS>
+__device__ __forceinline__ double tone_trig(double w)
 {
-    const double inv = 0.15915494309189533577;           // 1 / (2 pi)
-    const double c1 = 6.28318530717958623200e+00;         // 2 pi, leading 53 bits
-    const double c2 = 2.44929359829470641435e-16;         // next bits
-    const double c3 = -5.989539619436679e-33;             // and the next
-    const double k = rint(w * inv);
-    double r = fma(-k, c1, w);
-    r = fma(-k, c2, r);
-    r = fma(-k, c3, r);
-    return r;
+    const double two_over_pi = 0.63661977236758134308;
+    const double c1 = 1.57079632679489655800e+00;   // pi/2, leading 53 bits
+    const double c2 = 6.12323399573676603587e-17;   // next bits
+    const double c3 = -1.49738490485916983145e-33;  // and the next
+    const double k = rint(w * two_over_pi);
+    double t = fma(-k, c1, w);
+    t = fma(-k, c2, t);
+    t = fma(-k, c3, t);
+    int q = (int)(long long)k;
+    if (COS) q += 1;  // cos(w) = sin(w + pi/2)
+    const bool even = (q & 1) != 0;  // odd quadrant count: the even function (cosine) of t
+    const double z = t * t;
+    // sin(t) = t + t*z*S(z), cos(t) = 1 - z/2 + z*z*C(z)   (coefficients of fdlibm's kernels)
+    double p = even ? -1.13596475577881948265e-11 : 1.58969099521155010221e-10;
+    p = fma(p, z, even ? 2.08757232129817482790e-09 : -2.50507602534068634195e-08);
+    p = fma(p, z, even ? -2.75573143513906633035e-07 : 2.75573137070700676789e-06);
+    p = fma(p, z, even ? 2.48015872894767294178e-05 : -1.98412698298579493134e-04);
+    p = fma(p, z, even ? -1.38888888888741095749e-03 : 8.33333333332248946124e-03);
+    p = fma(p, z, even ? 4.16666666666666019037e-02 : -1.66666666666666324348e-01);
+    const double odd_val = fma(t * z, p, t);
+    const double even_val = fma(z * z, p, fma(-0.5, z, 1.0));
+    const double v = even ? even_val : odd_val;
+    return (q & 2) ? -v : v;
 }
-__device__ __forceinline__ double tone_sin(double w) { return sin(fabs(w) < 3.2 ? w : reduce_2pi(w)); }
-__device__ __forceinline__ double tone_cos(double w) { return cos(fabs(w) < 3.2 ? w : reduce_2pi(w)); }
+__device__ __forceinline__ double tone_sin(double w) { return tone_trig<false>(w); }
+__device__ __forceinline__ double tone_cos(double w) { return tone_trig<true>(w); }
 
 // mode 0: ps = |X| / sum if sum > 1e-5 else |X|      (fft/src/main.c:120-141)
 // mode 1: ps = |X| / sum                             (alsa/main.c:473-487)
@@ -187,42 +204,79 @@ __global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x
 }
 
 // ---- the same generator, parallel in time ---------------------------------------------
-// The recurrence w += dw is sequential, but it is cheap next to the cosines.  Pass 1 walks it
-// alone (one lane per channel and tone) and records the running angle at the start of every
-// 256-sample chunk; pass 2 gives every chunk to its own lane, which replays the same 256
-// additions from the recorded angle -- bit for bit the values the sequential kernel sees --
-// and evaluates the tones.  64 consecutive chunks of a channel form a workgroup, transposed
-// through LDS so the stores are contiguous.
-constexpr unsigned kToneChunk = 256;
-
-__global__ __launch_bounds__(64) void tonegen_phase_kernel(double *__restrict__ w, const double *__restrict__ dw,
-                                                           double *__restrict__ wstart, unsigned n, unsigned nseq)
+// The recurrence w = fl(w + dw) is sequential, but its rounding is regular: while w stays in one
+// binade [2^e, 2^(e+1)) it is a multiple M*u of that binade's unit u = 2^(e-52), and adding dw
+// then rounds to M + D with one fixed integer D (dw/u rounded to nearest; on an exact tie the
+// result is the even neighbour, which is again a fixed step once M is even).  So the additions
+// inside a binade collapse into one integer multiply-add, and only the additions that cross into
+// the next binade are performed for real.  advance() returns bit for bit what `steps` sequential
+// additions produce, in a number of iterations proportional to the binades crossed, and every
+// 256-sample chunk of the signal can start from its own exactly known angle.
+__device__ __forceinline__ double advance(double a, double d, unsigned long long steps)
 {
-    const unsigned s = blockIdx.x * 64 + threadIdx.x;  // (channel, tone) pair
-    if (s >= nseq) return;
-    const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
-    double a = w[s];
-    const double d = dw[s];
-    for (unsigned c = 0; c < nchunk; c++) {
-        wstart[(size_t)s * nchunk + c] = a;
-        const unsigned len = min(kToneChunk, n - c * kToneChunk);
-        if (len == kToneChunk) {
-            // a bare chain of dependent additions: nothing but the adder's latency per sample
-#pragma unroll
-            for (unsigned i = 0; i < kToneChunk; i++) {
-                a += d;
-                asm volatile("" : "+v"(a));  // keep the additions separate and in order
-            }
-        } else {
-            for (unsigned i = 0; i < len; i++) a += d;
-        }
+    constexpr unsigned long long kMant = (1ull << 52) - 1, kOne = 1ull << 52;
+    if (!(a >= 0.0) || !(d > 0.0)) {
+        // negative or NaN operands: no shortcut, walk the additions
+        for (; steps; steps--) a += d;
+        return a;
     }
-    w[s] = a;
+    const unsigned long long id = (unsigned long long)__double_as_longlong(d);
+    const int ed = (int)(id >> 52);  // d > 0: sign bit clear
+    const unsigned long long md = ed ? ((id & kMant) | kOne) : (id & kMant);
+    const int ed_eff = ed ? ed : 1;
+    while (steps) {
+        const unsigned long long ia = (unsigned long long)__double_as_longlong(a);
+        const int ea = (int)(ia >> 52);
+        const int sh = ea - ed_eff;  // dw / u = md / 2^sh
+        if (ea == 0 || ea == 0x7ff || sh <= 0) {
+            // zero, subnormal or infinite angle, or an increment at least as large as the
+            // angle's binade: this addition changes the binade, do it for real
+            a += d;
+            steps--;
+            continue;
+        }
+        if (sh >= 54) return a;  // dw < u/2: the angle no longer moves
+        const unsigned long long M = (ia & kMant) | kOne;
+        const unsigned long long q = md >> sh, r = md & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        unsigned long long D;
+        if (r > half) D = q + 1;
+        else if (r < half) D = q;
+        else if (M & 1) {
+            a += d;  // tie from an odd multiple: one real step makes it even
+            steps--;
+            continue;
+        } else D = q + (q & 1);
+        if (D == 0) return a;
+        // additions whose exact sum stays below 2^(e+1) round on this binade's grid
+        const unsigned long long lim = (1ull << 53) - 1 - q;
+        if (M > lim) {
+            a += d;
+            steps--;
+            continue;
+        }
+        unsigned long long n = (lim - M) / D + 1;
+        if (n > steps) n = steps;
+        const unsigned long long M2 = M + n * D;  // <= 2^53
+        const unsigned long long bits = (M2 >> 53) ? ((unsigned long long)(ea + 1) << 52) : (((unsigned long long)ea << 52) | (M2 & kMant));
+        a = __longlong_as_double((long long)bits);
+        steps -= n;
+    }
+    return a;
 }
+
+// running angles after a call: one lane per (channel, tone)
+__global__ __launch_bounds__(64) void tonegen_finish_kernel(double *__restrict__ w, const double *__restrict__ dw, unsigned n,
+                                                            unsigned nseq)
+{
+    const unsigned s = blockIdx.x * 64 + threadIdx.x;
+    if (s < nseq) w[s] = advance(w[s], dw[s], n);
+}
+
+constexpr unsigned kToneChunk = 256;
 
 template <typename O>
 __global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, size_t x_stride, unsigned n,
-                                                           unsigned ntone, const double *__restrict__ wstart,
+                                                           unsigned ntone, const double *__restrict__ w,
                                                            const double *__restrict__ dw, const double *__restrict__ amp,
                                                            const double *__restrict__ phi, int use_sin)
 {
@@ -239,8 +293,8 @@ __global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, si
     for (int j = 0; j < MAXT; j++) {
         const bool on = live && j < (int)ntone;
         const size_t s = (size_t)chan * ntone + j;
-        wl[j] = on ? wstart[s * nchunk + chunk] : 0.0;
         dwl[j] = on ? dw[s] : 0.0;
+        wl[j] = on ? advance(w[s], dwl[j], (unsigned long long)chunk * kToneChunk) : 0.0;
         al[j] = on ? amp[s] : 0.0;
         pl[j] = on ? phi[s] : 0.0;
     }
@@ -292,37 +346,31 @@ int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigne
     return DSPMI_OK;
 }
 
-size_t dspmi_tonegen_work_bytes(unsigned n, unsigned nchan, unsigned ntone)
-{
-    return (size_t)nchan * ntone * ((n + kToneChunk - 1) / kToneChunk) * sizeof(double);
-}
-
 }  // extern "C"
 
 namespace {
 
 template <typename O>
 int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
-                const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
+                const double *amp, const double *phi, int use_sin, unsigned flags, void *stream)
 {
     if (n == 0 || nchan == 0) return DSPMI_OK;
     if (!x || !w || !dw || (!use_sin && (!amp || !phi))) return dspmi::fail(DSPMI_EINVAL, "tonegen: null buffer");
     if (ntone == 0 || ntone > 8) return dspmi::fail(DSPMI_ENOSYS, "tonegen: 1..8 tones per channel on the device (got %u)", ntone);
     if (x_stride < n) return dspmi::fail(DSPMI_EINVAL, "tonegen: x_stride < n");
     if (use_sin && (!amp || !phi)) amp = phi = dw;  // never read in the sine form
-    if (work && work_bytes >= dspmi_tonegen_work_bytes(n, nchan, ntone)) {
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        double *wstart = static_cast<double *>(work);
-        const unsigned nseq = nchan * ntone;
-        const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
-        hipLaunchKernelGGL(tonegen_phase_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, wstart, n, nseq);
-        hipLaunchKernelGGL(tonegen_chunk_kernel<O>, dim3(nchan * ((nchunk + 63) / 64)), dim3(64), 0, s, x, x_stride, n, ntone,
-                           wstart, dw, amp, phi, use_sin);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & DSPMI_TONEGEN_SEQUENTIAL) {
+        hipLaunchKernelGGL(tonegen_kernel<O>, dim3((nchan + 63) / 64), dim3(64), 0, s, x, x_stride, n, nchan, ntone, w, dw, amp, phi,
+                           use_sin);
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
-    hipLaunchKernelGGL(tonegen_kernel<O>, dim3((nchan + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), x, x_stride, n,
-                       nchan, ntone, w, dw, amp, phi, use_sin);
+    const unsigned nseq = nchan * ntone;
+    const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
+    hipLaunchKernelGGL(tonegen_chunk_kernel<O>, dim3(nchan * ((nchunk + 63) / 64)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp,
+                       phi, use_sin);
+    hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
@@ -332,17 +380,16 @@ int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned nton
 extern "C" {
 
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
-                      const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
+                      const double *amp, const double *phi, int use_sin, unsigned flags, void *stream)
 {
-    return tonegen_run<float>(x, x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, work, work_bytes, stream);
+    return tonegen_run<float>(x, x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, flags, stream);
 }
 
 int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
-                        const double *amp, const double *phi, int use_sin, void *work, size_t work_bytes, void *stream)
+                        const double *amp, const double *phi, int use_sin, unsigned flags, void *stream)
 {
     if (reinterpret_cast<uintptr_t>(x) & 3) return dspmi::fail(DSPMI_EINVAL, "tonegen: output must be 4-byte aligned");
-    return tonegen_run<int>(reinterpret_cast<int *>(x), x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, work, work_bytes,
-                            stream);
+    return tonegen_run<int>(reinterpret_cast<int *>(x), x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, flags, stream);
 }
 
 }  // extern "C"

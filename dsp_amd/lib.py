@@ -60,9 +60,8 @@ _SIGS = {
     "dspmi_fft_exec_r2c_spectrum": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_fft_exec_r2c_spectrum_s16x2": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
-    "dspmi_tonegen_work_bytes": (_sz, [_u, _u, _u]),
-    "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
-    "dspmi_tonegen_s16x2": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
+    "dspmi_tonegen_s16x2": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),
@@ -304,36 +303,25 @@ class ToneGen:
         self.w = torch.zeros_like(self.dw)
 
     def read(self, n, out=None, sequential=False):
-        """Next n samples of every channel.  sequential=True walks each channel with one lane
-        (no scratch); the default replays recorded chunk phases in parallel -- same bits."""
+        """Next n samples of every channel.  sequential=True walks each channel with one lane;
+        the default jumps to every chunk's exact starting angle and fills the chunks in parallel
+        -- same bits."""
         import torch
         if out is None:
             out = torch.empty((self.nchan, n), dtype=torch.float32, device=self.w.device)
         assert out.shape == (self.nchan, n) and out.stride(1) == 1
-        wp, wb = None, 0
-        if not sequential:
-            wb = lib().dspmi_tonegen_work_bytes(n, self.nchan, self.ntone)
-            if getattr(self, "_work", None) is None or self._work.numel() < wb:
-                self._work = torch.empty(wb, dtype=torch.uint8, device=self.w.device)
-            wp = self._work.data_ptr()
         _check(lib().dspmi_tonegen_f32(out.data_ptr(), out.stride(0) if self.nchan > 1 else n, n, self.nchan, self.ntone,
                                        self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
-                                       int(self.use_sin), wp, wb, _stream()), "tonegen")
+                                       int(self.use_sin), 1 if sequential else 0, _stream()), "tonegen")
         return out
 
     def read_s16x2(self, n, sequential=False):
         """Next n samples of every channel as stereo int16 frames [nchan, n, 2] (both channels equal)."""
         import torch
         out = torch.empty((self.nchan, n, 2), dtype=torch.int16, device=self.w.device)
-        wp, wb = None, 0
-        if not sequential:
-            wb = lib().dspmi_tonegen_work_bytes(n, self.nchan, self.ntone)
-            if getattr(self, "_work", None) is None or self._work.numel() < wb:
-                self._work = torch.empty(wb, dtype=torch.uint8, device=self.w.device)
-            wp = self._work.data_ptr()
         _check(lib().dspmi_tonegen_s16x2(out.data_ptr(), n, n, self.nchan, self.ntone,
                                          self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
-                                         int(self.use_sin), wp, wb, _stream()), "tonegen_s16x2")
+                                         int(self.use_sin), 1 if sequential else 0, _stream()), "tonegen_s16x2")
         return out
 
 

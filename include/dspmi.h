@@ -204,21 +204,23 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from
  * call to call.  use_sin != 0 selects the unit-amplitude sine form of fft/src/main.c:281-290
  * (amp and phi unused).  ntone <= 8.
- * work: optional device scratch of dspmi_tonegen_work_bytes(n, nchan, ntone) bytes; with it the
- * call is parallel in time as well as over channels (the running angle at the start of every
- * 256-sample chunk is recorded first, then the chunks are replayed independently: the same
- * additions, so the same bits); without it (NULL) one lane walks each channel. */
-size_t dspmi_tonegen_work_bytes(unsigned n, unsigned nchan, unsigned ntone);
+ * The call is parallel in time as well as over channels: the running angle at the start of
+ * every 256-sample chunk is computed exactly (the rounded additions inside one binade of the
+ * angle are a fixed integer step, so they are applied in one go; additions that cross a binade
+ * are performed), then the chunks are generated independently -- the same angles, bit for bit,
+ * as the sequential recurrence.  DSPMI_TONEGEN_SEQUENTIAL walks each channel with one lane
+ * instead (the recurrence as written; for checking). */
+#define DSPMI_TONEGEN_SEQUENTIAL 1u
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
                       double *w, const double *dw, const double *amp, const double *phi,
-                      int use_sin, void *work, size_t work_bytes, void *stream);
+                      int use_sin, unsigned flags, void *stream);
 /* Same generator, samples stored as interleaved 16-bit stereo frames: (int16_t)value in both
  * channels (convert_double_to_s16x2, tonegen/main.c:14-24).  x_stride in frames.  The sum is
  * formed in double as above; its cosines may differ from the host libm's in the last bit, so a
  * sample whose exact value lies within ~1e-12 of an integer can come out one step apart. */
 int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
                         double *w, const double *dw, const double *amp, const double *phi,
-                        int use_sin, void *work, size_t work_bytes, void *stream);
+                        int use_sin, unsigned flags, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Host drop-in wrappers (reference signatures; host double buffers)         */

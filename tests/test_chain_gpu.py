@@ -36,6 +36,46 @@ def test_power_spectrum_modes(nbin):
         assert abs(got1[0].sum() - 1.0) < 1e-5
 
 
+def test_tonegen_phase_jumps_are_the_sequential_additions():
+    """The time-parallel generator reaches every chunk's starting angle by collapsing the rounded
+    additions of one binade into an integer step.  Bit for bit the one-lane walk, over increments
+    from far below the angle's rounding unit to far above the angle, exact rounding ties
+    (increments of 1.5, 2.5 ... units of the angle's last place), odd and even starting
+    multiples, zero and tiny starting angles, and negative increments (no shortcut)."""
+    rng = np.random.default_rng(7)
+    nchan, ntone = 512, 8
+    dw = 10.0 ** rng.uniform(-13, 3, (nchan, ntone))
+    w0 = np.where(rng.random((nchan, ntone)) < 0.3, 0.0, 10.0 ** rng.uniform(-8, 7, (nchan, ntone)))
+    # exact ties: angle in [2^20, 2^21) has unit 2^-32; increments (q + 1/2) units
+    ulp = 2.0 ** -32
+    for i in range(64):
+        w0[i, 0] = 2.0 ** 20 + ulp * (i * 977 + (i & 1))          # odd and even multiples
+        dw[i, 0] = ulp * (rng.integers(0, 5) + 0.5)
+        w0[i, 1] = 2.0 ** 21 - ulp * rng.integers(1, 2000)        # about to cross a binade
+        dw[i, 1] = ulp * (rng.integers(1, 1 << 20) + 0.5)
+        dw[i, 2] = -abs(dw[i, 2])                                 # negative: walked, not jumped
+        w0[i, 3] = 5e-324 * rng.integers(0, 50)                   # subnormal start
+    gens = []
+    for _ in range(2):
+        g = dsp_amd.ToneGen(48000.0, np.ones((nchan, ntone)), np.ones((nchan, ntone)), np.zeros((nchan, ntone)))
+        g.dw.copy_(torch.from_numpy(dw).cuda())
+        g.w.copy_(torch.from_numpy(w0).cuda())
+        gens.append(g)
+    for n in (3000, 1, 255, 257, 40000):
+        a = gens[0].read(n, sequential=True)
+        b = gens[1].read(n)
+        assert torch.equal(gens[0].w, gens[1].w), n
+        assert torch.equal(a, b), n
+    # and the walk itself is the host's: a few sequences replayed in numpy
+    wend = gens[1].w.cpu().numpy()
+    for c, j in ((0, 0), (1, 1), (5, 2), (100, 4), (511, 7)):
+        acc = np.float64(w0[c, j])
+        d = np.float64(dw[c, j])
+        for _ in range(3000 + 1 + 255 + 257 + 40000):
+            acc = acc + d
+        assert acc == wend[c, j], (c, j)
+
+
 def test_tonegen_matches_recurrence_and_continues():
     fs = 48000.0
     freqs = np.array([[100.0 * (c + 1), 12000.0] for c in range(70)])
