@@ -171,7 +171,11 @@ def make_long(args, rank, use_ols):
         kernel = "ols_fft%d" % plan.fft_length
         fn = lambda: plan.exec(x, y=y)
     else:
-        plan = dsp_amd.FirPlan(taps, "f32")
+        os.environ["DSPMI_FIR_VARIANT"] = "mfma"   # pin the direct kernel (the plan alone would pick overlap-save)
+        try:
+            plan = dsp_amd.FirPlan(taps, "f32")
+        finally:
+            del os.environ["DSPMI_FIR_VARIANT"]
         kernel = plan.variant
         fn = lambda: plan.exec(x, args.long_samples, y=y)
     info = dict(kernel=kernel, units=args.long_samples, unit_name="samples", nh=nh,
