@@ -437,41 +437,56 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
             for (int r = 0; r < RLAST; r++) lds[pad(tl + NT * b + r * NSLAST)] = v[b * RLAST + r];
         frame_sync<NT>();
 
-        // bins k = tl + NT*i, i < P; the lane with k = 0 also forms bin N (Nyquist)
-        C<T> x[P];
-        C<T> nyq = {T(0), T(0)};
+        // Bins come in pairs: with E, O the even / odd half-transforms,
+        //   X[k] = E[k] + W^k O[k],   X[N-k] = conj(E[k] - W^k O[k]),   W = exp(-2 pi i / 2N),
+        // so one pair of LDS reads and one twiddle give two bins.  A lane forms the pairs
+        // k = tl + NT*i, i < P/2 (k = 0 pairs bin 0 with the Nyquist bin N); lane 0 adds the
+        // self-paired bin N/2 = conj(Z[N/2]).
+        constexpr int H = P / 2;
+        // The lane index is laundered through an empty asm: otherwise every address, offset and
+        // twiddle below is loop-invariant, gets hoisted out of the frame loop and occupies ~50
+        // registers through the transform passes (2 waves per SIMD instead of 3-4).
+        unsigned te = tl;
+        asm volatile("" : "+v"(te));
+        C<T> xlo[H], xhi[H];
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-            const unsigned k = tl + NT * i;
+        for (int i = 0; i < H; i++) {
+            const unsigned k = te + NT * i;
             const C<T> a = lds[pad(k)];
             const C<T> b0 = lds[pad((N - k) & (N - 1))];
             const C<T> e = {(a.re + b0.re) * T(0.5), (a.im - b0.im) * T(0.5)};
             const C<T> d = {(a.re - b0.re) * T(0.5), (a.im + b0.im) * T(0.5)};
             const C<T> o = {d.im, -d.re};  // -i * d
-            const C<T> w = tw2n[k];        // exp(-2 pi i k / 2N)
-            const C<T> wo = cmul(w, o);
-            x[i] = {e.re + wo.re, e.im + wo.im};
-            if (k == 0) nyq = {a.re - a.im, T(0)};
+            const C<T> wo = cmul(tw2n[k], o);
+            xlo[i] = {e.re + wo.re, e.im + wo.im};
+            xhi[i] = {e.re - wo.re, wo.im - e.im};
         }
+        const C<T> zmid = lds[pad(N / 2)];
+        const C<T> xmid = {zmid.re, -zmid.im};
         frame_sync<NT>();  // reads done before the next frame's passes overwrite the image
 
         if constexpr (EPI == 1) {
             C<T> *dst = static_cast<C<T> *>(out_raw) + frame * (N + 1);
             if (active) {
 #pragma unroll
-                for (int i = 0; i < P; i++) nt_store(x[i], &dst[tl + NT * i]);
-                if (tl == 0) dst[N] = nyq;
+                for (int i = 0; i < H; i++) {
+                    nt_store(xlo[i], &dst[te + NT * i]);
+                    nt_store(xhi[i], &dst[N - (te + NT * i)]);
+                }
+                if (tl == 0) dst[N / 2] = xmid;
             }
         } else {
-            float mag[P];
+            float mlo[H], mhi[H];
             float part = 0.f;
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                mag[i] = sqrtf((float)(x[i].re * x[i].re + x[i].im * x[i].im));
-                part += mag[i];
+            for (int i = 0; i < H; i++) {
+                mlo[i] = sqrtf((float)(xlo[i].re * xlo[i].re + xlo[i].im * xlo[i].im));
+                mhi[i] = sqrtf((float)(xhi[i].re * xhi[i].re + xhi[i].im * xhi[i].im));
+                // bin N (the partner of bin 0) belongs to the spectrum only when nbin = N + 1
+                part += mlo[i] + ((i == 0 && tl == 0 && nbin <= N) ? 0.f : mhi[i]);
             }
-            const float mnyq = fabsf((float)nyq.re);
-            if (tl == 0 && nbin > N) part += mnyq;
+            const float mmid = sqrtf((float)(xmid.re * xmid.re + xmid.im * xmid.im));
+            if (tl == 0) part += mmid;
             float div = 1.f, mul = 1.f;
             if (mode == 2) {
                 mul = 2.f;
@@ -483,8 +498,12 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
             float *dst = static_cast<float *>(out_raw) + frame * nbin;
             if (active) {
 #pragma unroll
-                for (int i = 0; i < P; i++) __builtin_nontemporal_store((mul * mag[i]) / div, &dst[tl + NT * i]);
-                if (tl == 0 && nbin > N) dst[N] = (mul * mnyq) / div;
+                for (int i = 0; i < H; i++) {
+                    const unsigned k = te + NT * i;
+                    __builtin_nontemporal_store((mul * mlo[i]) / div, &dst[k]);
+                    if (N - k < nbin) __builtin_nontemporal_store((mul * mhi[i]) / div, &dst[N - k]);
+                }
+                if (tl == 0) dst[N / 2] = (mul * mmid) / div;
             }
         }
     }
@@ -588,7 +607,11 @@ __global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_pe
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
         // spectrum times H, conjugated for the backward transform (conj . forward . conj)
         {
-            const C<T> *hp = a.H + tl;
+            // laundered lane index: H[...] is the same for every frame, and hoisting its 2*P
+            // values out of the frame loop would cost their registers through both transforms
+            unsigned th = tl;
+            asm volatile("" : "+v"(th));
+            const C<T> *hp = a.H + th;
 #pragma unroll
             for (int i = 0; i < P; i++) {
                 const C<T> hq = hp[NT * (i / R0) + (i % R0) * STEP];

@@ -58,7 +58,12 @@ int dspmi_device_count(void);
  * alsa/main.c:389-407). */
 typedef struct dspmi_fir_plan *dspmi_fir_t;
 
-/* taps: nh HOST values, h[0] first.  device < 0 means the current device. */
+/* taps: nh HOST values, h[0] first.  device < 0 means the current device.
+ * An f32 plan of 96..8192 taps also prepares an overlap-save path (the frequency-domain
+ * convolution doc/notes:81-82 names; same outputs to the same 1e-6 bound with fewer flops),
+ * which dspmi_fir_exec_f32 uses when flags == 0, nxx == nx and the rows hold at least two
+ * transforms; every other call runs the direct kernel.  DSPMI_FIR_VARIANT=mfma in the
+ * environment at creation pins the direct kernel. */
 int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device);
 int dspmi_fir_create_f64(dspmi_fir_t *plan, const double *taps, unsigned nh, int device);
 int dspmi_fir_destroy(dspmi_fir_t plan);
