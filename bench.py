@@ -252,6 +252,8 @@ def measured_traffic(info):
         key = "fft_f32_n1024 x 1048576 frames"
     elif "nh" in info and info["units"] == 512 << 20 and "mfma" in info["kernel"]:
         key = "fir_f32_mfma 512 ch x 1048576 samples"
+    elif info.get("nh") == 127 and info["units"] == 512 << 20 and info["kernel"] == "fir_f32_overlap_save_n1024":
+        key = "fir_f32_overlap_save_n1024 512 ch x 1048576 samples, 127 taps"
     return tab[key]["hbm_bytes"] if key in tab else None
 
 
