@@ -44,6 +44,23 @@ KERNEL(k_pk_mov, "v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]")
         for (int i = 0; i < 32; i++) t += v[i];                                                \
         out[blockIdx.x * 256 + threadIdx.x] = t;                                               \
     }
+// cross-lane moves: the register-only alternatives to an LDS exchange between FFT passes
+#define KERNEL_X(NAME, ASM)                                                                    \
+    __global__ __launch_bounds__(256) void NAME(float* out, const float* in, int iters)       \
+    {                                                                                          \
+        float v[32];                                                                           \
+        for (int i = 0; i < 32; i++) v[i] = in[threadIdx.x + i];                               \
+        for (int it = 0; it < iters; it++) {                                                   \
+            _Pragma("unroll") for (int u = 0; u < 32; u += 2) { asm volatile(ASM : "+v"(v[u]), "+v"(v[u + 1])); } \
+        }                                                                                      \
+        float t = 0;                                                                           \
+        for (int i = 0; i < 32; i++) t += v[i];                                                \
+        out[blockIdx.x * 256 + threadIdx.x] = t;                                               \
+    }
+KERNEL_X(k_permlane32_swap, "v_permlane32_swap_b32 %0, %1")
+KERNEL_X(k_permlane16_swap, "v_permlane16_swap_b32 %0, %1")
+KERNEL_X(k_dpp_row_shr, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf")
+KERNEL_X(k_dpp_quad_perm, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 KERNEL_S(k_add2, "v_add_f32 %0, %1, %0")
 KERNEL_S(k_fma2, "v_fma_f32 %0, %1, %2, %0")
 KERNEL_S(k_mov2, "v_mov_b32 %0, %1")
@@ -77,5 +94,6 @@ int main()
     }
     RUN(k_pk_fma, 1) RUN(k_pk_fma_sel, 1) RUN(k_pk_fma_neg, 1) RUN(k_pk_add, 1) RUN(k_pk_add_sel, 1) RUN(k_pk_add_neg, 1)
     RUN(k_pk_mul, 1) RUN(k_pk_mul_sel, 1) RUN(k_pk_mov, 1) RUN(k_add2, 2) RUN(k_fma2, 2) RUN(k_mov2, 2)
+    RUN(k_permlane32_swap, 1) RUN(k_permlane16_swap, 1) RUN(k_dpp_row_shr, 1) RUN(k_dpp_quad_perm, 1)
     return 0;
 }
