@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +15,33 @@ namespace dspmi {
 // Thread-local last-error text, read through dspmi_last_error().
 char *errbuf();
 int fail(int code, const char *fmt, ...);
+
+// A plan's buffers live on the device it was created for; executing it while another device is
+// current would launch on that other device with foreign pointers.  Returns DSPMI_OK or fails.
+inline int check_device(int plan_device, const char *what)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail(DSPMI_EIO, "%s: hipGetDevice failed", what);
+    if (cur != plan_device)
+        return fail(DSPMI_EINVAL, "%s: the plan belongs to device %d but device %d is current", what, plan_device, cur);
+    return DSPMI_OK;
+}
+
+// Kernel attributes (the dynamic-LDS limit) are per device: a launcher keeps one of these per
+// kernel and sets the attribute the first time it runs on each device.  Two threads may both
+// find the bit clear and both set the attribute -- harmless; the bit is set only afterwards, so
+// nobody launches before the attribute is in place.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    static unsigned long long bit()
+    {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool pending() const { return (done.load(std::memory_order_acquire) & bit()) == 0; }
+    void mark() { done.fetch_or(bit(), std::memory_order_release); }
+};
 
 }  // namespace dspmi
 

@@ -505,6 +505,7 @@ int dspmi_fft_destroy(dspmi_fft_t plan)
 int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, int sign, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_c2c")) return rc;
     if (sign != DSPMI_FORWARD && sign != DSPMI_BACKWARD) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: sign must be -1 or +1");
     if (batch == 0) return DSPMI_OK;
     if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null buffer");
@@ -521,6 +522,7 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
 int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_r2c")) return rc;
     if (batch == 0) return DSPMI_OK;
     if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c: null buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -530,6 +532,7 @@ int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
 int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_c2r")) return rc;
     if (batch == 0) return DSPMI_OK;
     if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2r: null buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -540,6 +543,7 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
                                 float scale, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_r2c_spectrum")) return rc;
     if (plan->precision != DSPMI_F32) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_r2c_spectrum: f32 plans only");
     if (batch == 0) return DSPMI_OK;
     if (!in || !ps) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: null buffer");
@@ -561,6 +565,7 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
                                       float scale, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_r2c_spectrum_s16x2")) return rc;
     if (plan->precision != DSPMI_F32) return dspmi::fail(DSPMI_ENOSYS, "fft_exec_r2c_spectrum_s16x2: f32 plans only");
     if (batch == 0) return DSPMI_OK;
     if (!in || !ps) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: null buffer");

@@ -662,10 +662,10 @@ int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_
     constexpr int FPB = BT / NT;
     constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<float>);
     auto kern = ols_fused_kernel<N, NT, R0, R1, R2, R3, TW>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    static dspmi::PerDeviceOnce attr;
+    if (lds > 48 * 1024 && attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr.mark();
     }
     OlsArgs a;
     a.x = o.x; a.hist = o.hist; a.y = o.y; a.H = static_cast<const C<float> *>(o.H);
@@ -712,11 +712,11 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     constexpr size_t tw_entries = lds_twiddle_entries(TW, R0, R1, R2, R3);
     constexpr size_t lds = single_pass ? 0 : ((size_t)FPB * padded_len(N) + tw_entries) * sizeof(C<T>);
     auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TW, PREFETCH, NTMEM>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    static dspmi::PerDeviceOnce attr;
+    if (lds > 48 * 1024 && attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-        attr_set = true;
+        attr.mark();
     }
     if (batch == 0) return DSPMI_OK;
     const size_t nfb = (batch + FPB - 1) / FPB;
@@ -758,11 +758,11 @@ int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size
                            (size_t)FPB * (NT > 64 ? NT / 64 : 1) * sizeof(float);
     auto k1 = fft_r2c_kernel<T, N, NT, R0, R1, R2, R3, TW, 1>;
     auto k2 = fft_r2c_kernel<T, N, NT, R0, R1, R2, R3, TW, 2>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    static dspmi::PerDeviceOnce attr;
+    if (lds > 48 * 1024 && attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr.mark();
     }
     if (batch == 0) return DSPMI_OK;
     const int pcm = (epilogue & dspmi::kR2cSourceS16x2) != 0;

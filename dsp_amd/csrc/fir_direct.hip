@@ -535,11 +535,11 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
     auto k_small = fir_mfma_kernel<(TILE + 256 + 255) / 256, TPW>;      // segments up to 256 taps
     auto k_large = fir_mfma_kernel<(TILE + kMfmaSeg + 255) / 256, TPW>;  // up to kMfmaSeg taps
-    static bool attr_done = false;
-    if (!attr_done) {
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_large), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(seg <= 256 ? k_small : k_large, dim3(blocks), dim3(256), lds, stream, p);
     DSPMI_HIP(hipGetLastError());
@@ -627,6 +627,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
          unsigned nchan, const T *hist, size_t hist_stride, unsigned flags, void *stream, int precision, bool desc)
 {
     if (!pl) return dspmi::fail(DSPMI_EINVAL, "fir_exec: null plan");
+    if (int rc = dspmi::check_device(pl->device, "fir_exec")) return rc;
     if (pl->precision != precision) return dspmi::fail(DSPMI_EINVAL, "fir_exec: plan precision mismatch");
     if (nchan == 0 || nxx == 0) return DSPMI_OK;
     if (!y || (!x && nx)) return dspmi::fail(DSPMI_EINVAL, "fir_exec: null buffer");
@@ -711,6 +712,7 @@ int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, cons
                          unsigned nsampl, unsigned nblock, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fir_exec_s16x2")) return rc;
     if (plan->precision != DSPMI_F64)
         return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: needs a double-precision plan (results are exact integers)");
     if (nsampl == 0 || nblock == 0) return DSPMI_OK;

@@ -177,6 +177,7 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
                        unsigned nchan, const float *hist, size_t hist_stride, void *stream)
 {
     if (!plan) return dspmi::fail(DSPMI_EINVAL, "ols_exec: null plan");
+    if (int rc = dspmi::check_device(plan->device, "ols_exec")) return rc;
     if (nx == 0 || nchan == 0) return DSPMI_OK;
     if (!x || !y) return dspmi::fail(DSPMI_EINVAL, "ols_exec: null buffer");
     if (x_stride < nx || y_stride < nx) return dspmi::fail(DSPMI_EINVAL, "ols_exec: stride smaller than the row length");
