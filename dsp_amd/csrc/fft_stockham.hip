@@ -145,6 +145,17 @@ __device__ __forceinline__ void frame_sync()
     }
 }
 
+// The lane index as the transform passes see it.  With twiddles read from the global table
+// (TW == 0) every twiddle load has a loop-invariant address, and the compiler hoists all of them
+// out of the frame loop -- hundreds of registers, spilled to scratch.  Passing the index through
+// an empty asm once per frame makes the loads per-frame again (they hit L1 / L2).
+template <int TW>
+__device__ __forceinline__ unsigned pass_lane(unsigned tl)
+{
+    if constexpr (TW == 0) asm volatile("" : "+v"(tl));
+    return tl;
+}
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // Number of twiddle registers (complex) pass `R` with P points per lane needs.
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
         C<T> *dst = out + frame * N;
 #pragma unroll
         for (int i = 0; i < P; i++) v[i].im *= sgn;
-        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
         // last pass writes global memory: butterfly j, output r goes to j + r*N/RLAST
         if (active) {
 #pragma unroll
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
                 }
                 v[b * R0 + r] = q;
             }
-        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
 
         // park Z in natural order (the last pass's LDS reads are behind a frame_sync already)
 #pragma unroll
@@ -604,7 +615,7 @@ __global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_pe
             frame_sync<NT>();
         }
 
-        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
         // spectrum times H, conjugated for the backward transform (conj . forward . conj)
         {
             // laundered lane index: H[...] is the same for every frame, and hoisting its 2*P
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_pe
                 v[i] = {m.re, -m.im};
             }
         }
-        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
 
         // outputs j = m - (nh-1) >= 0 of each block of the pair
         if (interior) {
