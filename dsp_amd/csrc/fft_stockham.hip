@@ -537,7 +537,7 @@ struct OlsArgs {
 // forward transform's last pass (j + r*N/R) are exactly the ones the backward transform's
 // first pass wants: the spectrum is multiplied in registers and goes straight back in.
 template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
-__global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_per_eu(3, 8))) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
+__global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_per_eu((N / NT > 16) ? 2 : 3, 8))) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
 {
     typedef float T;
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
@@ -707,7 +707,7 @@ const OlsEntry kOls[] = {
     OLS(16, 1, 16, 1, 1, 1, 0),        OLS(32, 2, 4, 2, 4, 1, 2),          OLS(64, 4, 4, 4, 4, 1, 2),
     OLS(128, 8, 4, 8, 4, 1, 2),        OLS(256, 16, 16, 16, 1, 1, 2),      OLS(512, 32, 16, 2, 16, 1, 2),
     OLS(1024, 64, 16, 4, 16, 1, 2),    OLS(2048, 128, 16, 8, 16, 1, 2),    OLS(4096, 256, 16, 16, 16, 1, 2),
-    OLS(8192, 512, 16, 16, 2, 16, 2),  OLS(16384, 1024, 16, 16, 4, 16, 0),
+    OLS(8192, 512, 16, 16, 2, 16, 2),  OLS(16384, 512, 16, 16, 4, 16, 0),
 };
 
 // ---------------------------------------------------------------------------
