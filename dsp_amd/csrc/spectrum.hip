@@ -212,53 +212,55 @@ __global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x
 // the next binade are performed for real.  advance() returns bit for bit what `steps` sequential
 // additions produce, in a number of iterations proportional to the binades crossed, and every
 // 256-sample chunk of the signal can start from its own exactly known angle.
-__device__ __forceinline__ double advance(double a, double d, unsigned long long steps)
+// The run of additions that stays on one binade's grid: starting from a (>= 0) with increment
+// d (> 0), a_k = a + k*step exactly for every k <= n.  n == 0 means the next addition has to be
+// performed for real (it changes the binade, or starts from zero / a subnormal / an odd multiple
+// on an exact tie); step == 0 with n = all ones means the angle no longer moves.
+__device__ __forceinline__ unsigned long long fixed_run(double a, double d, double &step)
 {
     constexpr unsigned long long kMant = (1ull << 52) - 1, kOne = 1ull << 52;
+    step = 0.0;
+    const unsigned long long id = (unsigned long long)__double_as_longlong(d);
+    const int ed = (int)(id >> 52);  // d > 0: sign bit clear
+    const unsigned long long md = ed ? ((id & kMant) | kOne) : (id & kMant);
+    const unsigned long long ia = (unsigned long long)__double_as_longlong(a);
+    const int ea = (int)(ia >> 52);
+    const int sh = ea - (ed ? ed : 1);  // d / u = md / 2^sh, u = the unit of a's binade
+    if (ea == 0 || ea == 0x7ff || sh <= 0) return 0;
+    if (sh >= 54) return ~0ull;  // d < u/2
+    const unsigned long long M = (ia & kMant) | kOne;
+    const unsigned long long q = md >> sh, r = md & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+    unsigned long long D;
+    if (r > half) D = q + 1;
+    else if (r < half) D = q;
+    else if (M & 1) return 0;  // tie from an odd multiple: one real addition makes it even
+    else D = q + (q & 1);
+    if (D == 0) return ~0ull;
+    // additions whose exact sum stays below 2^(e+1) round on this binade's grid
+    const unsigned long long lim = (1ull << 53) - 1 - q;
+    if (M > lim) return 0;
+    step = ldexp((double)D, ea - 1075);  // D * u, exact
+    return (lim - M) / D + 1;
+}
+
+__device__ __forceinline__ double advance(double a, double d, unsigned long long steps)
+{
     if (!(a >= 0.0) || !(d > 0.0)) {
         // negative or NaN operands: no shortcut, walk the additions
         for (; steps; steps--) a += d;
         return a;
     }
-    const unsigned long long id = (unsigned long long)__double_as_longlong(d);
-    const int ed = (int)(id >> 52);  // d > 0: sign bit clear
-    const unsigned long long md = ed ? ((id & kMant) | kOne) : (id & kMant);
-    const int ed_eff = ed ? ed : 1;
     while (steps) {
-        const unsigned long long ia = (unsigned long long)__double_as_longlong(a);
-        const int ea = (int)(ia >> 52);
-        const int sh = ea - ed_eff;  // dw / u = md / 2^sh
-        if (ea == 0 || ea == 0x7ff || sh <= 0) {
-            // zero, subnormal or infinite angle, or an increment at least as large as the
-            // angle's binade: this addition changes the binade, do it for real
+        double step;
+        unsigned long long n = fixed_run(a, d, step);
+        if (n == 0) {
             a += d;
             steps--;
             continue;
         }
-        if (sh >= 54) return a;  // dw < u/2: the angle no longer moves
-        const unsigned long long M = (ia & kMant) | kOne;
-        const unsigned long long q = md >> sh, r = md & ((1ull << sh) - 1), half = 1ull << (sh - 1);
-        unsigned long long D;
-        if (r > half) D = q + 1;
-        else if (r < half) D = q;
-        else if (M & 1) {
-            a += d;  // tie from an odd multiple: one real step makes it even
-            steps--;
-            continue;
-        } else D = q + (q & 1);
-        if (D == 0) return a;
-        // additions whose exact sum stays below 2^(e+1) round on this binade's grid
-        const unsigned long long lim = (1ull << 53) - 1 - q;
-        if (M > lim) {
-            a += d;
-            steps--;
-            continue;
-        }
-        unsigned long long n = (lim - M) / D + 1;
+        if (step == 0.0) return a;
         if (n > steps) n = steps;
-        const unsigned long long M2 = M + n * D;  // <= 2^53
-        const unsigned long long bits = (M2 >> 53) ? ((unsigned long long)(ea + 1) << 52) : (((unsigned long long)ea << 52) | (M2 & kMant));
-        a = __longlong_as_double((long long)bits);
+        a = fma((double)n, step, a);  // the exact value is representable (at most 2^53 units): no rounding
         steps -= n;
     }
     return a;
@@ -274,6 +276,13 @@ __global__ __launch_bounds__(64) void tonegen_finish_kernel(double *__restrict__
 
 constexpr unsigned kToneChunk = 256;
 
+// One lane per 256-sample chunk.  Where the chunk's angles stay on one binade's grid (all but
+// the few chunks in which an angle crosses a power of two), they are a_k = a_0 + k*step exactly,
+// so cos / sin follow by rotating (cos a_0, sin a_0) by the fixed angle `step`: four multiply-adds
+// per sample and tone instead of an evaluation, with ~3e-14 of accumulated rounding over the
+// chunk.  The reference rounds the sum angle + phase before taking the cosine; that rounding is
+// recovered exactly (two-sum) and applied as a first-order correction.  Other chunks evaluate
+// every sample directly.
 template <typename O>
 __global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, size_t x_stride, unsigned n,
                                                            unsigned ntone, const double *__restrict__ w,
@@ -289,6 +298,8 @@ __global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, si
     const bool live = chunk < nchunk;
     constexpr int MAXT = 8;
     double wl[MAXT], dwl[MAXT], al[MAXT], pl[MAXT];
+    double stp[MAXT], cs[MAXT], sn[MAXT], cd[MAXT], sd[MAXT];
+    bool rotate = true;
 #pragma unroll
     for (int j = 0; j < MAXT; j++) {
         const bool on = live && j < (int)ntone;
@@ -296,21 +307,71 @@ __global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, si
         dwl[j] = on ? dw[s] : 0.0;
         wl[j] = on ? advance(w[s], dwl[j], (unsigned long long)chunk * kToneChunk) : 0.0;
         al[j] = on ? amp[s] : 0.0;
-        pl[j] = on ? phi[s] : 0.0;
+        pl[j] = (on && !use_sin) ? phi[s] : 0.0;
+        stp[j] = cs[j] = sn[j] = cd[j] = sd[j] = 0.0;
+        if (on) {
+            const bool ok = wl[j] >= 0.0 && dwl[j] > 0.0 && fixed_run(wl[j], dwl[j], stp[j]) >= kToneChunk - 1;
+            rotate = rotate && ok;
+        }
+    }
+    if (rotate) {
+#pragma unroll
+        for (int j = 0; j < MAXT; j++) {
+            if (j < (int)ntone) {
+                // cos / sin of the exact angle a_0 + phase: of the rounded sum, corrected by its residual
+                const double sum = wl[j] + pl[j];
+                const double bb = sum - wl[j];
+                const double err = (wl[j] - (sum - bb)) + (pl[j] - bb);  // a_0 + phase = sum + err
+                const double c0 = tone_cos(sum), s0 = tone_sin(sum);
+                cs[j] = fma(-err, s0, c0);
+                sn[j] = fma(err, c0, s0);
+                cd[j] = tone_cos(stp[j]);
+                sd[j] = tone_sin(stp[j]);
+            }
+        }
     }
     O *xrow = x + (size_t)chan * x_stride;
     const size_t first = (size_t)(blockIdx.x - chan * groups) * 64 * kToneChunk;  // sample of lane 0, step 0
     for (unsigned base = 0; base < kToneChunk; base += 64) {
-        for (unsigned i = 0; i < 64; i++) {
-            double v = 0.0;
+        if (rotate) {
+            for (unsigned i = 0; i < 64; i++) {
+                double v = 0.0;
 #pragma unroll
-            for (int j = 0; j < MAXT; j++) {
-                if (j < (int)ntone) {
-                    v += use_sin ? tone_sin(wl[j]) : al[j] * tone_cos(wl[j] + pl[j]);
-                    wl[j] += dwl[j];
+                for (int j = 0; j < MAXT; j++) {
+                    if (j < (int)ntone) {
+                        if (use_sin) {
+                            v += sn[j];
+                        } else {
+                            double c = cs[j];
+                            if (pl[j] != 0.0) {
+                                // the reference's angle is fl(a_k + phase) = (a_k + phase) - err
+                                const double ak = fma((double)(base + i), stp[j], wl[j]);
+                                const double sum = ak + pl[j];
+                                const double bb = sum - ak;
+                                const double err = (ak - (sum - bb)) + (pl[j] - bb);
+                                c = fma(err, sn[j], c);
+                            }
+                            v += al[j] * c;
+                        }
+                        const double cn = fma(cs[j], cd[j], -(sn[j] * sd[j]));
+                        sn[j] = fma(sn[j], cd[j], cs[j] * sd[j]);
+                        cs[j] = cn;
+                    }
                 }
+                tile[lane][i] = tone_out<O>(v);
             }
-            tile[lane][i] = tone_out<O>(v);
+        } else {
+            for (unsigned i = 0; i < 64; i++) {
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < MAXT; j++) {
+                    if (j < (int)ntone) {
+                        v += use_sin ? tone_sin(wl[j]) : al[j] * tone_cos(wl[j] + pl[j]);
+                        wl[j] += dwl[j];
+                    }
+                }
+                tile[lane][i] = tone_out<O>(v);
+            }
         }
         __syncthreads();
         for (unsigned r = 0; r < 64; r++) {

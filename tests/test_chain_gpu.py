@@ -36,6 +36,14 @@ def test_power_spectrum_modes(nbin):
         assert abs(got1[0].sum() - 1.0) < 1e-5
 
 
+def same_samples(a, b, scale):
+    """The time-parallel generator steps cos / sin by rotation inside a chunk where the one-lane
+    walk evaluates them afresh: the double sums agree to ~1e-13, so the f32 samples are the same
+    except where a sum sits on a rounding boundary (then one unit in the last place apart)."""
+    d = (a.double() - b.double()).abs()
+    return bool(d.max() <= 1.3e-7 * scale) and float((d == 0).double().mean()) >= 0.9999
+
+
 def test_tonegen_phase_jumps_are_the_sequential_additions():
     """The time-parallel generator reaches every chunk's starting angle by collapsing the rounded
     additions of one binade into an integer step.  Bit for bit the one-lane walk, over increments
@@ -65,7 +73,7 @@ def test_tonegen_phase_jumps_are_the_sequential_additions():
         a = gens[0].read(n, sequential=True)
         b = gens[1].read(n)
         assert torch.equal(gens[0].w, gens[1].w), n
-        assert torch.equal(a, b), n
+        assert same_samples(a, b, 8.0), n
     # and the walk itself is the host's: a few sequences replayed in numpy
     wend = gens[1].w.cpu().numpy()
     for c, j in ((0, 0), (1, 1), (5, 2), (100, 4), (511, 7)):
@@ -91,10 +99,10 @@ def test_tonegen_matches_recurrence_and_continues():
         want = t.read(1333)
         got = np.concatenate([a[c], b[c]])
         assert np.abs(got - want.astype(np.float32)).max() <= 2e-7 * 1.5   # f32 rounding of a double sum
-    # the time-parallel form replays the same additions: identical bits to the one-lane walk
+    # the time-parallel form reaches the same angles (identical running phases); see same_samples
     g_seq, g_par = dsp_amd.ToneGen(fs, freqs, amps, phis), dsp_amd.ToneGen(fs, freqs, amps, phis)
     for n in (1000, 333, 70000):
-        assert torch.equal(g_seq.read(n, sequential=True), g_par.read(n))
+        assert same_samples(g_seq.read(n, sequential=True), g_par.read(n), 1.5)
     assert torch.equal(g_seq.w, g_par.w)
     # the sine form of fft/src/main.c:265-291
     g2 = dsp_amd.ToneGen(fs, [[100.0, 12000.0]], use_sin=True)
