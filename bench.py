@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir127_direct", "fir16", "fir8191", "ols8191", "chain"])
+    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir127_direct", "fir16", "c1", "fir8191", "ols8191", "chain"])
     ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
@@ -310,26 +310,35 @@ def cpu_baseline_fft(n=1024, target_s=12.0):
 
 
 def cpu_baseline_fir(nh, target_s=8.0):
-    """`convolve` of the reference restated (double, ascending taps), one thread, -O3."""
+    """One thread on the host.  With the reference's own conv0 at hand (oracle/_ref, compiled from
+    convolution/main.c where that tree was mounted) and a filter it was written for (tens of taps),
+    that routine is timed ("reference"); otherwise `convolve` restated in the oracle, -O3 ("port")."""
     import ctypes as C
     import oracle
-    L = oracle.lib("_fast")
     rng = np.random.default_rng(0)
     nx = 1 << 16
     x = rng.uniform(-1, 1, nx)
     h = np.asarray(TAPS16 if nh == 16 else sinc_taps(nh), dtype=np.float64)
     y = np.empty(nx)
     dp = C.POINTER(C.c_double)
+    ref = oracle.ref_lib() if nh <= 64 else None
+    if ref is not None:
+        kind, what = "reference", "the reference's conv0 (convolution/main.c:15-33, gcc -O2)"
+        run = lambda: ref.ref_conv0(x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh, y.ctypes.data_as(dp))
+    else:
+        L = oracle.lib("_fast")
+        kind, what = "port", "convolve restated (double, gcc -O3)"
+        run = lambda: L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
     t0 = time.perf_counter()
-    L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
+    run()
     per = time.perf_counter() - t0
     reps = int(max(1, min(4096, target_s / per)))
     t0 = time.perf_counter()
     for _ in range(reps):
-        L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
+        run()
     dt = time.perf_counter() - t0
-    return {"value": float("%.4g" % (reps * nx / dt / 1e9)), "unit": "Gsamples/s", "cores": 1, "kind": "port",
-            "sample": "%d blocks of %d samples, %d taps (double, gcc -O3, 1 thread)" % (reps, nx, nh)}
+    return {"value": float("%.4g" % (reps * nx / dt / 1e9)), "unit": "Gsamples/s", "cores": 1, "kind": kind,
+            "sample": "%d blocks of %d samples, %d taps, %s, 1 thread" % (reps, nx, nh, what)}
 
 
 # ---------------------------------------------------------------------------
@@ -346,6 +355,10 @@ def main():
     elif args.workload in ("fir8191", "ols8191"):
         fn, info, keep = make_long(args, rank, args.workload == "ols8191")
         args.no_secondary = True
+    elif args.workload == "c1":
+        # BASELINE config 1: the 16-tap table over one 1M-sample signal (the reference's CPU-runnable case)
+        args.channels, args.samples, args.no_secondary = 1, 1 << 20, True
+        fn, info, keep = make_fir(args, rank, 16)
     else:
         fn, info, keep = make_fir(args, rank, 16 if args.workload == "fir16" else 127, direct=args.workload == "fir127_direct")
 
@@ -397,6 +410,18 @@ def main():
             "cpu_baseline": cpu,
             "secondary": secondary,
         }
+        if args.workload == "c1":
+            # the same signal through the drop-in host routine: double precision, host buffers in
+            # and out over PCIe, plan and device buffers created per call as the reference does
+            xh = np.random.default_rng(1).uniform(-1, 1, 1 << 20)
+            hh = np.asarray(TAPS16, dtype=np.float64)
+            dsp_amd.conv0(xh, hh)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dsp_amd.conv0(xh, hh)
+            wms = (time.perf_counter() - t0) / 5 * 1e3
+            line["host_wrapper"] = {"routine": "dsp_conv0 (double, host buffers, PCIe-inclusive)", "ms_per_call": round(wms, 3),
+                                    "gsamples_per_s": round((1 << 20) / wms / 1e6, 4)}
         if "fir_fft_ms" in info:
             line["fir_fft_stages_only"] = {"ms_per_step": round(info["fir_fft_ms"], 3),
                                            "gsamples_per_s": round(info["units"] / info["fir_fft_ms"] / 1e6, 2)}
