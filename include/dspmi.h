@@ -59,7 +59,7 @@ int dspmi_device_count(void);
 typedef struct dspmi_fir_plan *dspmi_fir_t;
 
 /* taps: nh HOST values, h[0] first.  device < 0 means the current device.
- * An f32 plan of 96..8192 taps also prepares an overlap-save path (the frequency-domain
+ * An f32 plan of 64..8192 taps also prepares an overlap-save path (the frequency-domain
  * convolution doc/notes:81-82 names; same outputs to the same 1e-6 bound with fewer flops),
  * which dspmi_fir_exec_f32 uses when flags == 0, nxx == nx and the rows hold at least two
  * transforms; every other call runs the direct kernel.  DSPMI_FIR_VARIANT=mfma in the

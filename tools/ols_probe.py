@@ -1,5 +1,5 @@
 """Overlap-save against the direct kernel for short and mid-length filters: time and error."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 import dsp_amd, oracle
@@ -8,13 +8,15 @@ nchan, nx = 512, 1 << 20
 torch.manual_seed(1)
 x = (torch.rand((nchan, nx), device="cuda") * 2 - 1)
 y = torch.empty_like(x)
-for nh in (127, 63, 255, 511):
+for nh in ([int(a) for a in sys.argv[1:]] or (127, 63, 255, 511)):
     taps = oracle.windowed_sinc_taps(nh).astype(np.float32)
     want = None
     xs = x[:2, :70000].cpu().numpy()
     want = np.stack([oracle.fir_batch_f32(xs[c:c + 1], taps, 70000)[0] for c in range(2)]) if hasattr(oracle, "fir_batch_f32") else None
+    os.environ["DSPMI_FIR_VARIANT"] = "mfma"
     d = dsp_amd.FirPlan(taps)
-    for n in (0, 512, 1024, 2048, 4096):
+    del os.environ["DSPMI_FIR_VARIANT"]
+    for n in (0, 512, 1024, 2048):
         try:
             plan = d if n == 0 else dsp_amd.OlsPlan(taps, fft_n=n)
         except Exception as e:
