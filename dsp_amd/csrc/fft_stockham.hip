@@ -812,7 +812,7 @@ const FftEntry kF32[] = {
     F32(2, 1, 2, 1, 1, 1),          F32(4, 1, 4, 1, 1, 1),          F32(8, 1, 8, 1, 1, 1),
     F32(16, 1, 16, 1, 1, 1),        F32(32, 2, 16, 2, 1, 1),        F32(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
-    F32P(1024, 64, 16, 16, 4, 1),   F32(2048, 128, 16, 16, 8, 1),   F32P(4096, 256, 16, 16, 16, 1),
+    F32P(1024, 64, 16, 16, 4, 1),   F32P(2048, 128, 16, 16, 8, 1),   F32P(4096, 256, 16, 16, 16, 1),
     F32P(8192, 512, 16, 16, 16, 2),
     // 16384 points fill the LDS with the frame alone: twiddles come from the global table
     {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 3>,
