@@ -8,9 +8,10 @@
 //    registers between the magnitude pass and the divide.
 //  * tone generator: sum of a*cos(w+phi) with the running-phase recurrence w += dw of
 //    tonegen/tonegen.c:25-40, kept in double so a stream continues exactly where the last
-//    chunk stopped.  The recurrence is sequential in time, so the parallelism is over
-//    channels: one lane per channel, 64 samples at a time, transposed through LDS so that
-//    the stores to the channel-major signal are coalesced.
+//    call stopped.  A sequential one-lane-per-channel kernel is the recurrence as written;
+//    the default kernel is parallel in time: it jumps to the exact angle of any sample
+//    (advance) and steps cos / sin by rotation where the angles form an exact arithmetic
+//    sequence.
 #include "common.h"
 
 #include <cstdint>
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x
 // inside a binade collapse into one integer multiply-add, and only the additions that cross into
 // the next binade are performed for real.  advance() returns bit for bit what `steps` sequential
 // additions produce, in a number of iterations proportional to the binades crossed, and every
-// 256-sample chunk of the signal can start from its own exactly known angle.
+// range of the signal can start from its own exactly known angle.
 // The run of additions that stays on one binade's grid: starting from a (>= 0) with increment
 // d (> 0), a_k = a + k*step exactly for every k <= n.  n == 0 means the next addition has to be
 // performed for real (it changes the binade, or starts from zero / a subnormal / an odd multiple
@@ -274,111 +275,114 @@ __global__ __launch_bounds__(64) void tonegen_finish_kernel(double *__restrict__
     if (s < nseq) w[s] = advance(w[s], dw[s], n);
 }
 
-constexpr unsigned kToneChunk = 256;
+// One wave per range of 16384 samples of one channel; lane l produces samples l, l + 64, ...,
+// so every store is 256 contiguous bytes.  The range is walked in segments inside which every
+// tone's angles stay on one binade's grid, a_k = a + k*step exactly (usually the whole range is
+// one segment; an angle crossing a power of two ends a segment, and the crossing addition is a
+// segment of one sample).  In a segment a lane evaluates cos / sin once, at its first sample,
+// and then turns them by the fixed angle 64*step per sample: four multiply-adds per sample and
+// tone, ~3e-14 of accumulated rounding over at most 256 turns.  The reference rounds
+// angle + phase before taking the cosine; that rounding is recovered exactly (two-sum) and
+// applied as a first-order correction.
+constexpr unsigned kToneSteps = 256;                // samples per lane
+constexpr unsigned kToneRange = 64 * kToneSteps;    // samples per wave
 
-// One lane per 256-sample chunk.  Where the chunk's angles stay on one binade's grid (all but
-// the few chunks in which an angle crosses a power of two), they are a_k = a_0 + k*step exactly,
-// so cos / sin follow by rotating (cos a_0, sin a_0) by the fixed angle `step`: four multiply-adds
-// per sample and tone instead of an evaluation, with ~3e-14 of accumulated rounding over the
-// chunk.  The reference rounds the sum angle + phase before taking the cosine; that rounding is
-// recovered exactly (two-sum) and applied as a first-order correction.  Other chunks evaluate
-// every sample directly.
-template <typename O>
-__global__ __launch_bounds__(64) void tonegen_chunk_kernel(O *__restrict__ x, size_t x_stride, unsigned n,
-                                                           unsigned ntone, const double *__restrict__ w,
-                                                           const double *__restrict__ dw, const double *__restrict__ amp,
-                                                           const double *__restrict__ phi, int use_sin)
+// MAXT: tones the instantiation can hold (the loops over tones are unrolled to it)
+template <typename O, int MAXT>
+__global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned ntone,
+                                                           const double *__restrict__ w, const double *__restrict__ dw,
+                                                           const double *__restrict__ amp, const double *__restrict__ phi,
+                                                           int use_sin)
 {
-    __shared__ O tile[64][65];
     const unsigned lane = threadIdx.x;
-    const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
-    const unsigned groups = (nchunk + 63) / 64;  // workgroups per channel
-    const unsigned chan = blockIdx.x / groups;
-    const unsigned chunk = (blockIdx.x - chan * groups) * 64 + lane;
-    const bool live = chunk < nchunk;
-    constexpr int MAXT = 8;
-    double wl[MAXT], dwl[MAXT], al[MAXT], pl[MAXT];
-    double stp[MAXT], cs[MAXT], sn[MAXT], cd[MAXT], sd[MAXT];
-    bool rotate = true;
+    const unsigned nrange = (n + kToneRange - 1) / kToneRange;
+    const unsigned chan = blockIdx.x / nrange;
+    const size_t first = (size_t)(blockIdx.x - chan * nrange) * kToneRange;
+    const unsigned len = (unsigned)min((size_t)kToneRange, (size_t)n - first);
+    double A[MAXT], dl[MAXT], al[MAXT], pl[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; j++) {
-        const bool on = live && j < (int)ntone;
+        const bool on = j < (int)ntone;
         const size_t s = (size_t)chan * ntone + j;
-        dwl[j] = on ? dw[s] : 0.0;
-        wl[j] = on ? advance(w[s], dwl[j], (unsigned long long)chunk * kToneChunk) : 0.0;
+        dl[j] = on ? dw[s] : 0.0;
+        A[j] = on ? advance(w[s], dl[j], first) : 0.0;  // angle at the range's first sample: the same for every lane
         al[j] = on ? amp[s] : 0.0;
         pl[j] = (on && !use_sin) ? phi[s] : 0.0;
-        stp[j] = cs[j] = sn[j] = cd[j] = sd[j] = 0.0;
-        if (on) {
-            const bool ok = wl[j] >= 0.0 && dwl[j] > 0.0 && fixed_run(wl[j], dwl[j], stp[j]) >= kToneChunk - 1;
-            rotate = rotate && ok;
-        }
     }
-    if (rotate) {
+    O *xrow = x + (size_t)chan * x_stride + first;
+
+    unsigned pos = 0;
+    while (pos < len) {
+        // the segment: as far as every tone's run reaches (one sample where a tone needs a real addition)
+        unsigned seg = len - pos;
+        double step[MAXT];
+        bool real_add[MAXT];
 #pragma unroll
         for (int j = 0; j < MAXT; j++) {
+            step[j] = 0.0;
+            real_add[j] = false;
             if (j < (int)ntone) {
-                // cos / sin of the exact angle a_0 + phase: of the rounded sum, corrected by its residual
-                const double sum = wl[j] + pl[j];
-                const double bb = sum - wl[j];
-                const double err = (wl[j] - (sum - bb)) + (pl[j] - bb);  // a_0 + phase = sum + err
+                const unsigned long long run = (A[j] >= 0.0 && dl[j] > 0.0) ? fixed_run(A[j], dl[j], step[j]) : 0;
+                real_add[j] = run == 0;
+                if (run < seg) seg = run == 0 ? 1 : (unsigned)run;
+            }
+        }
+        // this lane's samples in the segment: k = k0, k0 + 64, ... < pos + seg
+        const unsigned off = (lane - pos) & 63;  // k0 - pos
+        double a0[MAXT], st64[MAXT], cs[MAXT], sn[MAXT], cd[MAXT], sd[MAXT];
+        if (off < seg) {
+#pragma unroll
+            for (int j = 0; j < MAXT; j++) {
+                a0[j] = fma((double)off, step[j], A[j]);  // exact
+                st64[j] = 64.0 * step[j];
+                // cos / sin of the exact angle a + phase: of the rounded sum, corrected by its residual
+                const double sum = a0[j] + pl[j];
+                const double bb = sum - a0[j];
+                const double err = (a0[j] - (sum - bb)) + (pl[j] - bb);  // a + phase = sum + err
                 const double c0 = tone_cos(sum), s0 = tone_sin(sum);
                 cs[j] = fma(-err, s0, c0);
                 sn[j] = fma(err, c0, s0);
-                cd[j] = tone_cos(stp[j]);
-                sd[j] = tone_sin(stp[j]);
+                if (seg > 64) {
+                    cd[j] = tone_cos(st64[j]);
+                    sd[j] = tone_sin(st64[j]);
+                } else {
+                    cd[j] = 1.0;  // a single sample per lane: never turned
+                    sd[j] = 0.0;
+                }
+                if (j >= (int)ntone) al[j] = cs[j] = sn[j] = 0.0;  // idle slots add nothing
             }
-        }
-    }
-    O *xrow = x + (size_t)chan * x_stride;
-    const size_t first = (size_t)(blockIdx.x - chan * groups) * 64 * kToneChunk;  // sample of lane 0, step 0
-    for (unsigned base = 0; base < kToneChunk; base += 64) {
-        if (rotate) {
-            for (unsigned i = 0; i < 64; i++) {
+            unsigned i = 0;
+            for (unsigned k = pos + off; k < pos + seg; k += 64, i++) {
                 double v = 0.0;
 #pragma unroll
                 for (int j = 0; j < MAXT; j++) {
-                    if (j < (int)ntone) {
-                        if (use_sin) {
-                            v += sn[j];
-                        } else {
-                            double c = cs[j];
-                            if (pl[j] != 0.0) {
-                                // the reference's angle is fl(a_k + phase) = (a_k + phase) - err
-                                const double ak = fma((double)(base + i), stp[j], wl[j]);
-                                const double sum = ak + pl[j];
-                                const double bb = sum - ak;
-                                const double err = (ak - (sum - bb)) + (pl[j] - bb);
-                                c = fma(err, sn[j], c);
-                            }
-                            v += al[j] * c;
+                    if (use_sin) {
+                        v += sn[j];
+                    } else {
+                        double c = cs[j];
+                        if (pl[j] != 0.0) {
+                            // the reference's angle is fl(a_k + phase) = (a_k + phase) - err
+                            const double ak = fma((double)i, st64[j], a0[j]);
+                            const double sum = ak + pl[j];
+                            const double bb = sum - ak;
+                            const double err = (ak - (sum - bb)) + (pl[j] - bb);
+                            c = fma(err, sn[j], c);
                         }
-                        const double cn = fma(cs[j], cd[j], -(sn[j] * sd[j]));
-                        sn[j] = fma(sn[j], cd[j], cs[j] * sd[j]);
-                        cs[j] = cn;
+                        v += al[j] * c;
                     }
+                    const double cn = fma(cs[j], cd[j], -(sn[j] * sd[j]));
+                    sn[j] = fma(sn[j], cd[j], cs[j] * sd[j]);
+                    cs[j] = cn;
                 }
-                tile[lane][i] = tone_out<O>(v);
+                xrow[k] = tone_out<O>(v);
             }
-        } else {
-            for (unsigned i = 0; i < 64; i++) {
-                double v = 0.0;
+        }
+        // every lane moves the angles to the next segment's first sample
 #pragma unroll
-                for (int j = 0; j < MAXT; j++) {
-                    if (j < (int)ntone) {
-                        v += use_sin ? tone_sin(wl[j]) : al[j] * tone_cos(wl[j] + pl[j]);
-                        wl[j] += dwl[j];
-                    }
-                }
-                tile[lane][i] = tone_out<O>(v);
-            }
+        for (int j = 0; j < MAXT; j++) {
+            if (j < (int)ntone) A[j] = real_add[j] ? A[j] + dl[j] : fma((double)seg, step[j], A[j]);
         }
-        __syncthreads();
-        for (unsigned r = 0; r < 64; r++) {
-            const size_t smp = first + (size_t)r * kToneChunk + base + lane;
-            if (smp < n) xrow[smp] = tile[r][lane];
-        }
-        __syncthreads();
+        pos += seg;
     }
 }
 
@@ -428,9 +432,11 @@ int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned nton
         return DSPMI_OK;
     }
     const unsigned nseq = nchan * ntone;
-    const unsigned nchunk = (n + kToneChunk - 1) / kToneChunk;
-    hipLaunchKernelGGL(tonegen_chunk_kernel<O>, dim3(nchan * ((nchunk + 63) / 64)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp,
-                       phi, use_sin);
+    const unsigned long long nrange = (n + kToneRange - 1) / kToneRange;
+    if (nrange * nchan > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "tonegen: too many sample ranges for one launch");
+    auto kern = ntone == 1 ? tonegen_range_kernel<O, 1> : ntone == 2 ? tonegen_range_kernel<O, 2>
+              : ntone <= 4 ? tonegen_range_kernel<O, 4> : tonegen_range_kernel<O, 8>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrange * nchan)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp, phi, use_sin);
     hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;

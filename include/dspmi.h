@@ -210,11 +210,12 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
  * call to call.  use_sin != 0 selects the unit-amplitude sine form of fft/src/main.c:281-290
  * (amp and phi unused).  ntone <= 8.
  * The call is parallel in time as well as over channels: the running angle at the start of
- * every 256-sample chunk is computed exactly (the rounded additions inside one binade of the
+ * every 16384-sample range is computed exactly (the rounded additions inside one binade of the
  * angle are a fixed integer step, so they are applied in one go; additions that cross a binade
- * are performed), then the chunks are generated independently -- the same angles, bit for bit,
- * as the sequential recurrence.  DSPMI_TONEGEN_SEQUENTIAL walks each channel with one lane
- * instead (the recurrence as written; for checking). */
+ * are performed), then the ranges are generated independently from the same angles, bit for
+ * bit, as the sequential recurrence; inside a range cos / sin advance by rotation, which agrees
+ * with evaluating every sample to ~1e-14.  DSPMI_TONEGEN_SEQUENTIAL walks each channel with
+ * one lane instead (the recurrence as written; for checking). */
 #define DSPMI_TONEGEN_SEQUENTIAL 1u
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
                       double *w, const double *dw, const double *amp, const double *phi,
