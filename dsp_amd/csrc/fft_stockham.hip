@@ -265,6 +265,11 @@ __device__ __forceinline__ void run_passes(C<T> *v, C<T> *lds, const C<T> *tw1, 
 
 template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
 
+// The fused overlap-save kernel is latency-bound and its occupancy LDS-bound (frame images plus
+// one twiddle table per workgroup): eight 1024-point frames per workgroup share the table, which
+// fits 16 waves on a CU where four-frame workgroups fit 12.
+template <int N, int NT> constexpr int ols_block_threads() { return N == 1024 ? 512 : block_threads<NT>(); }
+
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T> *in, C<T> *out,
                                                                       const C<T> *__restrict__ tw, size_t batch,
@@ -537,12 +542,12 @@ struct OlsArgs {
 // forward transform's last pass (j + r*N/R) are exactly the ones the backward transform's
 // first pass wants: the spectrum is multiplied in registers and goes straight back in.
 template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
-__global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_per_eu((N / NT > 16) ? 2 : 3, 8))) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
+__global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu_waves_per_eu((N / NT > 16) ? 2 : (N == 1024 ? 4 : 3), 8))) void ols_fused_kernel(const OlsArgs a, const C<float> *__restrict__ tw)
 {
     typedef float T;
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
     constexpr int P = N / NT;
-    constexpr int BT = block_threads<NT>();
+    constexpr int BT = ols_block_threads<N, NT>();
     constexpr int FPB = BT / NT;
     constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
     constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(block_threads<NT>()) __attribute__((amdgpu_waves_pe
 template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
 int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_t s)
 {
-    constexpr int BT = block_threads<NT>();
+    constexpr int BT = ols_block_threads<N, NT>();
     constexpr int FPB = BT / NT;
     constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<float>);
     auto kern = ols_fused_kernel<N, NT, R0, R1, R2, R3, TW>;
