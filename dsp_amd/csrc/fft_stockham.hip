@@ -304,8 +304,36 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
 
     const size_t nfb = (batch + FPB - 1) / FPB;
 
+    // Short frames (fewer than 16 lanes each): a lane's own points are N/R0 apart and the lanes of
+    // a frame cover only 16*NT contiguous bytes, so direct global access would touch memory in
+    // 16-128 byte pieces.  The wave's 64/NT frames are contiguous in memory instead: they are
+    // moved as one 64*P-element run, 512 contiguous bytes per instruction, through the frames'
+    // LDS images.
+    constexpr bool STAGED = NT < 16;
+    constexpr int FPW = 64 / (NT < 64 ? NT : 64);  // frames per wave
+    const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    C<T> *wlds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)wv * FPW * padded_len(N);
+
     // first pass reads global memory: lane-contiguous, R0 loads N/R0 apart
     auto load_frame = [&](C<T> (&v)[P], size_t fb) {
+        if constexpr (STAGED) {
+            const size_t f0 = fb * FPB + (size_t)wv * FPW;
+            const C<T> *chunk = in + f0 * N;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const unsigned e = ln + 64 * i, fr = e / N, idx = e % N;
+                C<T> q = {T(0), T(0)};
+                if (f0 + fr < batch) q = (NTMEM & 1) ? nt_load(&chunk[e]) : chunk[e];
+                wlds[fr * padded_len(N) + pad(idx)] = q;
+            }
+            frame_sync<NT>();
+#pragma unroll
+            for (int b = 0; b < P / R0; b++)
+#pragma unroll
+                for (int r = 0; r < R0; r++) v[b * R0 + r] = lds[pad(tl + NT * b + r * (N / R0))];
+            frame_sync<NT>();
+            return;
+        }
         const size_t frame = fb * FPB + slot;
         const C<T> *src = in + frame * N;
         const bool active = frame < batch;
@@ -325,6 +353,31 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
 #pragma unroll
         for (int i = 0; i < P; i++) v[i].im *= sgn;
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
+        if constexpr (STAGED) {
+            // outputs to their natural places in the frame's image, then out as one contiguous run
+#pragma unroll
+            for (int b = 0; b < P / RLAST; b++)
+#pragma unroll
+                for (int r = 0; r < RLAST; r++) {
+                    C<T> q = v[b * RLAST + r];
+                    q.im *= sgn;
+                    lds[pad(tl + NT * b + r * NSLAST)] = q;
+                }
+            frame_sync<NT>();
+            const size_t f0 = fb * FPB + (size_t)wv * FPW;
+            C<T> *chunk = out + f0 * N;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const unsigned e = ln + 64 * i, fr = e / N, idx = e % N;
+                if (f0 + fr < batch) {
+                    const C<T> q = wlds[fr * padded_len(N) + pad(idx)];
+                    if constexpr ((NTMEM & 2) != 0) nt_store(q, &chunk[e]);
+                    else chunk[e] = q;
+                }
+            }
+            frame_sync<NT>();
+            return;
+        }
         // last pass writes global memory: butterfly j, output r goes to j + r*N/RLAST
         if (active) {
 #pragma unroll
@@ -726,7 +779,8 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     constexpr int FPB = BT / NT;
     constexpr bool single_pass = R1 == 1 && R2 == 1 && R3 == 1;  // global -> registers -> global
     constexpr size_t tw_entries = lds_twiddle_entries(TW, R0, R1, R2, R3);
-    constexpr size_t lds = single_pass ? 0 : ((size_t)FPB * padded_len(N) + tw_entries) * sizeof(C<T>);
+    constexpr bool staged = NT < 16;  // short frames move through their LDS images (see the kernel)
+    constexpr size_t lds = (single_pass && !staged) ? 0 : ((size_t)FPB * padded_len(N) + tw_entries) * sizeof(C<T>);
     auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TW, PREFETCH, NTMEM>;
     static dspmi::PerDeviceOnce attr;
     if (lds && attr.pending()) {
