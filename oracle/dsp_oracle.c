@@ -623,7 +623,12 @@ void oracle_fft_batch(const double *in, double *out, unsigned n,
     if (with_table) {
         double *tw = (double *)malloc((size_t)n * sizeof *tw);
         oracle_fft_make_table(tw, n, sign);
-        for (f = 0; f != nframes; f++)
+        /* frames are independent: with -fopenmp (the _fast build) they are
+         * spread over oracle_set_threads() threads for the all-cores baseline */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+        for (f = 0; f < nframes; f++)
             oracle_fft_radix2_table(in + (size_t)f * 2 * n, n,
                                     out + (size_t)f * 2 * n, tw);
         free(tw);
@@ -640,7 +645,27 @@ void oracle_convolve_batch(double *xx, unsigned nxx, const double *x,
                            unsigned nchan)
 {
     unsigned c;
-    for (c = 0; c != nchan; c++)
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (c = 0; c < nchan; c++)
         oracle_convolve(xx + (size_t)c * nxx, nxx, x + (size_t)c * nx, nx, h,
                         nh);
 }
+
+/* Threads the two batch loops above use in an OpenMP build (1 otherwise). */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_set_threads(int n)
+{
+    if (n > 0)
+        omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+#else
+int oracle_set_threads(int n)
+{
+    (void)n;
+    return 1;
+}
+#endif
