@@ -11,10 +11,15 @@
 //   dst[(j div Ns)*Ns*R + (j mod Ns) + r*Ns] = v[r]   (global for the last pass)
 //
 // Input and output are in natural order, so no bit-reversal pass exists.  The
-// twiddles come from a table built in double precision on the host; for the
-// f32 kernels each lane fetches its (frame-independent) twiddles once and
-// keeps them in registers while it loops over frames.  When NT <= 64 a frame
-// lives inside one wave and the passes need no workgroup barrier.
+// twiddles come from a table built in double precision on the host; the f32
+// kernels copy the entries their passes need into a per-workgroup LDS table
+// (registers stay free for the butterflies), the f64 and 16384-point kernels
+// read the global table.  When NT <= 64 a frame lives inside one wave and the
+// passes need no workgroup barrier.  Besides the plain c2c kernel the file holds
+// the fused real-input kernel (split and spectrum epilogues) and the fused
+// overlap-save kernel (forward transform, multiply, backward transform on chip).
+// It is compiled without SLP vectorisation: packed f32 instructions issue at half
+// rate on gfx950, so pairing scalars only costs register moves.
 //
 // Semantics are those of fftw_plan_dft_1d as the reference calls it
 // (fftc/main.c:31-43): unnormalised in both directions, sign -1 forward.
