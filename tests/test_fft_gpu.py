@@ -71,6 +71,28 @@ def test_c2c_in_place_and_odd_batches():
         assert err.item() <= TOL_FFT, batch
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n", [2, 8, 16, 32, 64, 128])
+def test_short_frames_ragged_batches(n, dtype):
+    """Frames shorter than 16 lanes travel through LDS as one contiguous run per wave: batches
+    that end inside a wave's run, in place and out of place, nothing written past the batch."""
+    plan = dsp_amd.FftPlan(n, dtype)
+    ct = torch.complex64 if dtype == "f32" else torch.complex128
+    tol = TOL_FFT if dtype == "f32" else TOL_F64
+    for batch in (1, 3, 63, 64, 65, 1000, 4099):
+        g = torch.Generator(device="cuda").manual_seed(batch + n)
+        z = torch.view_as_complex(torch.rand((batch, n, 2), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).to(ct)
+        big = torch.full((batch + 70, n), 7.0 + 0j, dtype=ct, device="cuda")
+        plan.c2c(z, out=big[:batch])
+        assert bool((big[batch:] == 7.0).all()), batch
+        buf = z.clone()
+        plan.c2c(buf, out=buf)
+        assert torch.equal(buf, big[:batch])
+        ref = torch.fft.fft(z.to(torch.complex128))
+        err = ((big[:batch].to(torch.complex128) - ref).abs().pow(2).sum(1).sqrt() / ref.abs().pow(2).sum(1).sqrt()).max()
+        assert err.item() <= tol, (batch, err.item())
+
+
 def test_known_answers():
     n = 1024
     plan = dsp_amd.FftPlan(n, "f32")
