@@ -41,7 +41,6 @@ struct FirParams {
     unsigned tiles_per_chan;
     unsigned flags;
     unsigned ntiles_total, tiles_per_block;  // MFMA kernel: tiles over all channels / per workgroup
-    int prio_mode;                           // MFMA kernel: wave-priority policy (see set_prio)
 };
 
 template <typename T> struct Vec4;
@@ -238,21 +237,9 @@ constexpr unsigned mfma_lds_floats(unsigned tile, unsigned seglen)
 // input window of unit u+1 is already on its way from HBM into registers, and
 // is written to LDS once the loop is done (one LDS buffer, two barriers).
 // NIT = staging registers per lane = ceil((tile + segment - 1) / 256).
-__device__ __forceinline__ void set_prio(int level)
-{
-    switch (level & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-
 template <int NIT, int TPW>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 {
-    if (p.prio_mode == 1) set_prio(blockIdx.x);
-    if (p.prio_mode == 3) set_prio(blockIdx.x >> 8);
     constexpr int kMfmaTile = mfma_tile(TPW);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *lds = reinterpret_cast<float *>(smem_raw);
@@ -401,8 +388,6 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
         const int seglen = cur.seglen;  // multiple of 16
         const bool last_seg = cur.seg0 + cur.seglen >= (int)p.nhp;
 
-        if (p.prio_mode == 2) set_prio(3);
-        if (p.prio_mode == 4) set_prio(blockIdx.x + (int)unit);
         const float *ap = hr + a_base;
         const float *bp = xs + b_base;
         // 16 window positions (4 MFMA steps per tile) per group; the vector ALU shares its
@@ -440,7 +425,6 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
             bp += kRow;
         }
 
-        if (p.prio_mode == 2) set_prio(0);
         if (last_seg) {
             // D layout: column n = lane&15, rows 4*(lane>>4) .. +3 -> 4 consecutive outputs per
             // lane; the wave's 64 lanes cover 1 KiB contiguously.
@@ -500,9 +484,7 @@ enum {
 const char *const kVariantName[] = {"fir_f32_mfma16x16x4", "fir_f32_valu_r4g4_b16", "fir_f32_valu_r8g2_b16",
                                     "fir_f64_exact_r4g2_b8"};
 
-// TPW: 256-output MFMA tiles per wave.  4 (4096 outputs per workgroup) for the HBM-bound short
-// filters; 8 for the MFMA-bound long ones (per-tile set-up, barriers and stores amortised
-// over twice the MFMA work, one A-operand read per 8 MFMAs).
+// TPW: 256-output MFMA tiles per wave (4 in use: 4096 outputs per workgroup).
 template <int TPW>
 int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream_t stream)
 {
@@ -518,10 +500,6 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
         const int bpc = env && atoi(env) > 0 ? atoi(env) : bpc_default;
         const size_t want = (160 * 1024) / bpc - 512;
         if (want > lds) lds = want;
-    }
-    {
-        const char *env = getenv("DSPMI_FIR_PRIO");
-        p.prio_mode = env ? atoi(env) : 0;
     }
     p.tiles_per_chan = (p.nxx + TILE - 1) / TILE;
     const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
@@ -548,9 +526,7 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
 
 int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 {
-    const char *env = getenv("DSPMI_FIR_TPW");
-    const int tpw = env && atoi(env) > 0 ? atoi(env) : 4;  // 8 measured no faster at 127 taps
-    if (tpw == 8) return launch_mfma_t<8>(p, nchan, 4, stream);
+    // four 256-output tiles per wave (eight measured no faster at 127 taps)
     return launch_mfma_t<4>(p, nchan, p.nhp <= 64 ? 2 : 8, stream);
 }
 
@@ -636,7 +612,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     FirParams<T> p;
     p.y = y; p.x = x; p.hist = hist; p.taps = static_cast<const T *>(pl->taps_dev);
     p.y_stride = y_stride; p.x_stride = x_stride; p.hist_stride = hist_stride;
-    p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags; p.prio_mode = 0;
+    p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if constexpr (sizeof(T) == 4) {
         // overlap-save covers the plain case: as many outputs as inputs, rows long enough to
@@ -732,7 +708,7 @@ int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, cons
     p.y = reinterpret_cast<double *>(out); p.x = reinterpret_cast<const double *>(in); p.hist = nullptr;
     p.taps = static_cast<const double *>(plan->taps_dev);
     p.y_stride = out_stride; p.x_stride = in_stride; p.hist_stride = 0;
-    p.nxx = nsampl; p.nx = nsampl; p.nh = plan->nh; p.nhp = plan->nhp; p.flags = 0; p.prio_mode = 0;
+    p.nxx = nsampl; p.nx = nsampl; p.nh = plan->nh; p.nhp = plan->nhp; p.flags = 0;
     p.tiles_per_chan = (nsampl + 2047) / 2048;
     return launch<double, 4, 2, 8, true, false, true>(p, nblock, static_cast<hipStream_t>(stream));
 }
