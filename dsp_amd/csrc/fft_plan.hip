@@ -437,6 +437,29 @@ bool is_pow2(unsigned n) { return n && (n & (n - 1)) == 0; }
 
 }  // namespace
 
+namespace {
+
+template <typename T>
+int filter_typed(dspmi_fft_plan *pl, const void *in, void *out, const void *gains, size_t batch, hipStream_t s)
+{
+    const unsigned n = pl->n, nbin = n / 2 + 1;
+    int rc = ensure_work(pl, 2, batch * (size_t)nbin * sizeof(C<T>));
+    if (rc != DSPMI_OK) return rc;
+    rc = r2c_typed<T>(pl, in, pl->work[2], batch, s);
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(bin_gain_kernel<T>, dim3(ew_grid(batch * nbin, pl->num_cu)), dim3(256), 0, s,
+                       static_cast<C<T> *>(pl->work[2]), static_cast<const T *>(gains), nbin, batch);
+    DSPMI_HIP(hipGetLastError());
+    rc = c2r_typed<T>(pl, pl->work[2], out, batch, s);
+    if (rc != DSPMI_OK) return rc;
+    hipLaunchKernelGGL(scale_kernel<T>, dim3(ew_grid(batch * (size_t)n, pl->num_cu)), dim3(256), 0, s, static_cast<T *>(out), (T)n,
+                       batch * (size_t)n);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
@@ -588,6 +611,17 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
     return dspmi_fft_exec_r2c_spectrum(plan, plan->work[3], ps, batch, nbin, mode, scale, stream);
 }
 
+int dspmi_fft_exec_filter(dspmi_fft_t plan, const void *in, void *out, const void *gains, size_t batch, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_filter: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_filter")) return rc;
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out || !gains) return dspmi::fail(DSPMI_EINVAL, "fft_exec_filter: null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return plan->precision == DSPMI_F64 ? filter_typed<double>(plan, in, out, gains, batch, s)
+                                        : filter_typed<float>(plan, in, out, gains, batch, s);
+}
+
 const char *dspmi_fft_variant(dspmi_fft_t plan)
 {
     return plan ? plan->name : "";
@@ -598,25 +632,10 @@ const char *dspmi_fft_variant(dspmi_fft_t plan)
 // Element-wise helpers used by the host wrappers.
 namespace dspmi {
 
-int bin_gain_f64(void *bins, const double *gain_dev, unsigned nbin, size_t batch, int num_cu, hipStream_t s)
-{
-    hipLaunchKernelGGL(bin_gain_kernel<double>, dim3(ew_grid(batch * nbin, num_cu)), dim3(256), 0, s,
-                       static_cast<C<double> *>(bins), gain_dev, nbin, batch);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
 int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride, hipStream_t s)
 {
     hipLaunchKernelGGL(ps_abs_kernel<double>, dim3(ew_grid(batch * nout, 256)), dim3(256), 0, s,
                        static_cast<const C<double> *>(bins), out, nout, scale, batch, in_stride);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
-int scale_f64(double *x, double divisor, size_t total, int num_cu, hipStream_t s)
-{
-    hipLaunchKernelGGL(scale_kernel<double>, dim3(ew_grid(total, num_cu)), dim3(256), 0, s, x, divisor, total);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }

@@ -16,8 +16,6 @@ int dspmi_fir_exec_f64_desc(dspmi_fir_t plan, double *y, size_t y_stride, unsign
                             size_t x_stride, unsigned nx, unsigned nchan, unsigned flags, void *stream);
 
 namespace dspmi {
-int bin_gain_f64(void *bins, const double *gain_dev, unsigned nbin, size_t batch, int num_cu, hipStream_t s);
-int scale_f64(double *x, double divisor, size_t total, int num_cu, hipStream_t s);
 int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride,
                hipStream_t s);
 }  // namespace dspmi
@@ -192,13 +190,10 @@ void dsp_filter(double *xx, const double *x, unsigned int n, const double *coeff
     dspmi_fft_t plan = nullptr;
     DSPMI_OR_DIE(dspmi_fft_create(&plan, n, DSPMI_F64, -1));
     const unsigned nbin = n / 2 + 1;
-    DevBuf dx((size_t)n * sizeof(double)), dbins((size_t)nbin * 2 * sizeof(double)), dg((size_t)nbin * sizeof(double));
+    DevBuf dx((size_t)n * sizeof(double)), dg((size_t)nbin * sizeof(double));
     DSPMI_HIP_OR_DIE(hipMemcpy(dx.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     DSPMI_HIP_OR_DIE(hipMemcpy(dg.p, coeffs, (size_t)nbin * sizeof(double), hipMemcpyHostToDevice));
-    DSPMI_OR_DIE(dspmi_fft_exec_r2c(plan, dx.p, dbins.p, 1, nullptr));
-    DSPMI_OR_DIE(dspmi::bin_gain_f64(dbins.p, dg.as<double>(), nbin, 1, 256, nullptr));
-    DSPMI_OR_DIE(dspmi_fft_exec_c2r(plan, dbins.p, dx.p, 1, nullptr));
-    DSPMI_OR_DIE(dspmi::scale_f64(dx.as<double>(), (double)n, n, 256, nullptr));
+    DSPMI_OR_DIE(dspmi_fft_exec_filter(plan, dx.p, dx.p, dg.p, 1, nullptr));
     DSPMI_HIP_OR_DIE(hipMemcpy(xx, dx.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     DSPMI_OR_DIE(dspmi_fft_destroy(plan));
 }

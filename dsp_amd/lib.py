@@ -52,6 +52,7 @@ _SIGS = {
     "dspmi_fft_exec_c2c": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp]),
     "dspmi_fft_exec_r2c": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "dspmi_fft_exec_c2r": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
+    "dspmi_fft_exec_filter": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "dspmi_fft_variant": (C.c_char_p, [_vp]),
     "dspmi_ols_create_f32": (C.c_int, [C.POINTER(_vp), _fp, _u, _u, C.c_int]),
     "dspmi_ols_destroy": (C.c_int, [_vp]),
@@ -245,6 +246,19 @@ class FftPlan:
         assert out.is_contiguous() and out.shape == (batch, nbin) and out.dtype == torch.float32
         _check(lib().dspmi_fft_exec_r2c_spectrum_s16x2(self._h, frames.data_ptr(), out.data_ptr(), batch, nbin, mode, scale,
                                                        _stream()), "fft_exec_r2c_spectrum_s16x2")
+        return out
+
+    def filter(self, x, gains, out=None):
+        """x: [batch, n] real frames; gains: [n//2 + 1] real per-bin gains -> filtered frames (util/filter/filter.c:73-105)."""
+        import torch
+        _, rt = self._types()
+        assert x.is_cuda and x.dtype == rt and x.is_contiguous() and x.shape[-1] == self.n
+        assert gains.is_cuda and gains.dtype == rt and gains.is_contiguous() and gains.numel() == self.n // 2 + 1
+        if out is None:
+            out = torch.empty_like(x)
+        assert out.is_cuda and out.dtype == rt and out.is_contiguous() and out.shape == x.shape
+        _check(lib().dspmi_fft_exec_filter(self._h, x.data_ptr(), out.data_ptr(), gains.data_ptr(), x.numel() // self.n,
+                                           _stream()), "fft_exec_filter")
         return out
 
     def c2r(self, x, out=None):

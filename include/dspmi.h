@@ -150,6 +150,13 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
 int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                        void *stream);
 
+/* Frequency-domain filtering of real frames, `filter` of util/filter/filter.c:73-105 per frame:
+ * forward real transform, every bin k <= n/2 scaled by the real gain gains[k], inverse real
+ * transform, divided by n.  in/out: [batch][n] reals of the plan's precision (may be the same
+ * buffer), gains: n/2+1 device reals. */
+int dspmi_fft_exec_filter(dspmi_fft_t plan, const void *in, void *out, const void *gains,
+                          size_t batch, void *stream);
+
 /* Backward transform of a Hermitian half spectrum: in [batch][n/2+1] complex,
  * out [batch][n] reals, unnormalised (fftw_plan_dft_c2r_1d,
  * util/filter/filter.c:100-101).  The input is left intact. */

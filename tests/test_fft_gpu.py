@@ -193,3 +193,24 @@ def test_real_transforms_any_length(n):
     gains = rng.uniform(0, 1, n // 2 + 1)
     assert rel_l2(dsp_amd.filter(x, gains), oracle.filter(x, gains)) <= 1e-12
     assert rel_l2(dsp_amd.filter(x, np.ones(n // 2 + 1)), x) <= 1e-12
+
+
+@pytest.mark.parametrize("dtype,n", [("f32", 4096), ("f32", 480), ("f32", 1001), ("f64", 4096), ("f64", 482)])
+def test_batched_filter_op(dtype, n):
+    """`filter` (util/filter/filter.c:73-105) as a batched device op, in place and out of place."""
+    rng = np.random.default_rng(n)
+    batch = 5
+    x = rng.uniform(-1, 1, (batch, n))
+    gains = np.where(np.arange(n // 2 + 1) < n // 8, 1.0, np.where(np.arange(n // 2 + 1) < n // 6, 0.5, 0.0))
+    rt = torch.float32 if dtype == "f32" else torch.float64
+    plan = dsp_amd.FftPlan(n, dtype)
+    xd = torch.from_numpy(x).to(rt).cuda()
+    gd = torch.from_numpy(gains).to(rt).cuda()
+    got = plan.filter(xd, gd).cpu().numpy()
+    buf = xd.clone()
+    plan.filter(buf, gd, out=buf)
+    assert np.array_equal(buf.cpu().numpy(), got)
+    tol = TOL_FFT if dtype == "f32" else TOL_F64
+    for f in range(batch):
+        want = oracle.filter(xd[f].double().cpu().numpy(), gains)
+        assert rel_l2(got[f], want) <= tol, (f, rel_l2(got[f], want))
