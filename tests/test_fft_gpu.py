@@ -195,7 +195,8 @@ def test_real_transforms_any_length(n):
     assert rel_l2(dsp_amd.filter(x, np.ones(n // 2 + 1)), x) <= 1e-12
 
 
-@pytest.mark.parametrize("dtype,n", [("f32", 4096), ("f32", 480), ("f32", 1001), ("f64", 4096), ("f64", 482)])
+@pytest.mark.parametrize("dtype,n", [("f32", 4096), ("f32", 16), ("f32", 1024), ("f32", 16384), ("f32", 8), ("f32", 480),
+                                     ("f32", 1001), ("f64", 4096), ("f64", 482)])
 def test_batched_filter_op(dtype, n):
     """`filter` (util/filter/filter.c:73-105) as a batched device op, in place and out of place."""
     rng = np.random.default_rng(n)
@@ -214,3 +215,20 @@ def test_batched_filter_op(dtype, n):
     for f in range(batch):
         want = oracle.filter(xd[f].double().cpu().numpy(), gains)
         assert rel_l2(got[f], want) <= tol, (f, rel_l2(got[f], want))
+
+
+@pytest.mark.parametrize("n,batch", [(1024, 1), (1024, 2), (2048, 7), (256, 64), (32, 33)])
+def test_filter_one_kernel_form_matches_the_composition(n, batch, monkeypatch):
+    """Power-of-two f32 frames take the one-kernel form (two real frames per complex transform, the
+    gains as a real even spectrum); the r2c / gain / c2r / scale composition is the same arithmetic."""
+    rng = np.random.default_rng(n + batch)
+    x = torch.from_numpy(rng.uniform(-1, 1, (batch, n)).astype(np.float32)).cuda()
+    gains = torch.from_numpy(rng.uniform(0, 2, n // 2 + 1).astype(np.float32)).cuda()
+    plan = dsp_amd.FftPlan(n, "f32")
+    fused = plan.filter(x, gains).cpu().numpy()
+    monkeypatch.setenv("DSPMI_FILTER_COMPOSED", "1")
+    composed = plan.filter(x, gains).cpu().numpy()
+    for f in range(batch):
+        want = oracle.filter(x[f].double().cpu().numpy(), gains.double().cpu().numpy())
+        assert rel_l2(fused[f], want) <= TOL_FFT, (f, rel_l2(fused[f], want))
+        assert rel_l2(composed[f], want) <= TOL_FFT
