@@ -22,12 +22,18 @@ constexpr int kR2cSourceS16x2 = 0x100;
 typedef int (*fft_r2c_launch_fn)(const void *in, void *out, const void *tw, const void *tw2n, size_t batch, int epilogue,
                                  unsigned nbin, int mode, float scale, int num_cu, hipStream_t s);
 
+// Real output through this N-point complex kernel: in = batch frames of N+1 bins, out = batch
+// frames of 2N reals (unnormalised); in and out must not overlap.
+typedef int (*fft_c2r_launch_fn)(const void *in, void *out, const void *tw, const void *tw2n, size_t batch, int num_cu,
+                                 hipStream_t s);
+
 struct FftKernel {
     unsigned n;
     fft_launch_fn fn;         // default cache policy
     fft_launch_fn fn_stream;  // nontemporal loads and stores: batches far larger than the caches
     const char *name;
     fft_r2c_launch_fn fn_r2c;  // fused real-input form, or nullptr
+    fft_c2r_launch_fn fn_c2r;  // fused real-output form, or nullptr
 };
 
 // Kernel for a power-of-two length, or nullptr.

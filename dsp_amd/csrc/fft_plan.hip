@@ -359,6 +359,14 @@ int setup_bluestein(dspmi_fft_plan *pl)
     return rc;
 }
 
+// Whether real transforms of this plan run the fused kernels (real <-> half-complex step inside
+// the transform kernel; they exist from 128 complex points up, tools/real_probe.py).
+// DSPMI_FFT_REAL_COMPOSED=1 selects the separate split / merge kernels everywhere (A/B knob).
+bool fused_real(const dspmi_fft_plan *pl)
+{
+    return pl->kern_half && pl->kern_half->fn_r2c && pl->kern_half->fn_c2r && !getenv("DSPMI_FFT_REAL_COMPOSED");
+}
+
 template <typename T>
 int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipStream_t s)
 {
@@ -369,7 +377,7 @@ int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
-    if (pl->kern_half && pl->kern_half->fn_r2c)  // fused: transform + split in one kernel
+    if (fused_real(pl))  // transform + split in one kernel
         return pl->kern_half->fn_r2c(in, out, pl->tw_half, pl->tw_n, batch, 1, n / 2 + 1, 0, 0.f, pl->num_cu, s);
     if (pl->kern_half) {
         int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
@@ -408,6 +416,15 @@ int c2r_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
                            static_cast<const C<T> *>(in), static_cast<T *>(out), batch);
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
+    }
+    if (fused_real(pl)) {
+        // merge + transform in one kernel.  Frames of bins and frames of samples have
+        // different lengths, so workgroups would trample each other's input in an overlapping
+        // buffer: that case takes the two-kernel route below.
+        const char *a = static_cast<const char *>(in), *b = static_cast<const char *>(out);
+        const size_t in_bytes = batch * (size_t)(n / 2 + 1) * sizeof(C<T>), out_bytes = batch * (size_t)n * sizeof(T);
+        if (a + in_bytes <= b || b + out_bytes <= a)
+            return pl->kern_half->fn_c2r(in, out, pl->tw_half, pl->tw_n, batch, pl->num_cu, s);
     }
     if (pl->kern_half) {
         int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
@@ -621,7 +638,7 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
     const unsigned n = plan->n;
     if (nbin == 0 || nbin > n / 2 + 1) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: nbin must be 1..n/2+1");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (plan->kern_half && plan->kern_half->fn_r2c && nbin >= n / 2)
+    if (fused_real(plan) && nbin >= n / 2)
         return plan->kern_half->fn_r2c(in, ps, plan->tw_half, plan->tw_n, batch, 2, nbin, mode, scale, plan->num_cu, s);
     // any other length: bins to scratch, then the stand-alone spectrum kernel
     int rc = ensure_work(plan, 2, batch * (size_t)(n / 2 + 1) * sizeof(C<float>));
@@ -645,7 +662,7 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
     const unsigned n = plan->n;
     if (nbin == 0 || nbin > n / 2 + 1) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: nbin must be 1..n/2+1");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (plan->kern_half && plan->kern_half->fn_r2c && nbin >= n / 2)
+    if (fused_real(plan) && nbin >= n / 2)
         return plan->kern_half->fn_r2c(in, ps, plan->tw_half, plan->tw_n, batch, 2 | dspmi::kR2cSourceS16x2, nbin, mode, scale,
                                        plan->num_cu, s);
     // any other length: convert to mono floats first

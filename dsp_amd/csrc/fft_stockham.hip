@@ -584,6 +584,90 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
 }
 
 // ---------------------------------------------------------------------------
+// real output: bins 0..N of a 2N-point real frame back to the frame
+// ---------------------------------------------------------------------------
+
+// The fftw_plan_dft_c2r_1d contract (util/filter/filter.c:98-103): unnormalised, the imaginary
+// parts of bins 0 and N ignored.  The 2N reals, read as N complex points, are the N-point
+// backward transform of
+//   Z[m] = (X[m] + conj X[N-m]) + i W^-m (X[m] - conj X[N-m]),   W = exp(-2 pi i / 2N).
+// A lane loads the bins its first pass wants (the c2c load pattern), the frame's LDS image
+// supplies each one's partner X[N-m] (bin N sits in the image's spare slot), and Z goes
+// straight into the passes: the merge costs no trip through HBM.
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW>
+__global__ __launch_bounds__(block_threads<NT>()) void fft_c2r_kernel(const C<T> *in, C<T> *out,
+                                                                      const C<T> *__restrict__ tw,
+                                                                      const C<T> *__restrict__ tw2n, size_t batch)
+{
+    static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
+    constexpr int P = N / NT;
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
+    constexpr int NSLAST = N / RLAST;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned slot = threadIdx.x / NT;
+    const unsigned tl = threadIdx.x % NT;
+    C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const size_t frame = fb * FPB + slot;
+        const bool active = frame < batch;
+        const C<T> *src = in + frame * (N + 1);
+        // laundered lane index: keeps the twiddle loads and partner addresses per-frame instead
+        // of hoisted out of the frame loop into registers that would live through the passes
+        unsigned te = tl;
+        asm volatile("" : "+v"(te));
+        C<T> v[P], w[P];
+#pragma unroll
+        for (int b = 0; b < P / R0; b++)
+#pragma unroll
+            for (int r = 0; r < R0; r++) {
+                const unsigned m = te + NT * b + r * (N / R0);
+                C<T> q = {T(0), T(0)};
+                if (active) q = nt_load(&src[m]);
+                v[b * R0 + r] = q;
+            }
+        // the merge twiddles are in flight together with the bins
+#pragma unroll
+        for (int i = 0; i < P; i++) w[i] = tw2n[te + NT * (i / R0) + (i % R0) * (N / R0)];
+#pragma unroll
+        for (int i = 0; i < P; i++) lds[pad(te + NT * (i / R0) + (i % R0) * (N / R0))] = v[i];
+        if (tl == 0) lds[pad(N)] = active ? src[N] : C<T>{T(0), T(0)};
+        frame_sync<NT>();
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const unsigned m = te + NT * (i / R0) + (i % R0) * (N / R0);
+            C<T> a = v[i];
+            C<T> b0 = lds[pad(N - m)];
+            if (i == 0 && te == 0) a.im = b0.im = T(0);  // m == 0: bins 0 and N
+            const C<T> sm = {a.re + b0.re, a.im - b0.im};
+            const C<T> d = {a.re - b0.re, a.im + b0.im};
+            const C<T> wd = cmul(C<T>{w[i].re, -w[i].im}, d);
+            // Z = sm + i*wd, conjugated for the backward transform (conj . forward . conj)
+            v[i] = {sm.re - wd.im, -(sm.im + wd.re)};
+        }
+        frame_sync<NT>();  // partners read before the passes overwrite the image
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
+        if (active) {
+            C<T> *dst = out + frame * N;
+#pragma unroll
+            for (int b = 0; b < P / RLAST; b++)
+#pragma unroll
+                for (int r = 0; r < RLAST; r++) {
+                    const C<T> q = v[b * RLAST + r];
+                    nt_store(C<T>{q.re, -q.im}, &dst[tl + NT * b + r * NSLAST]);
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // overlap-save: load two real blocks, transform, multiply by H, transform back, keep
 // the part that does not wrap -- one kernel, the block never leaves the CU
 // ---------------------------------------------------------------------------
@@ -856,31 +940,64 @@ int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size
     return DSPMI_OK;
 }
 
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW>
+int launch_c2r(const void *in, void *out, const void *tw, const void *tw2n, size_t batch, int num_cu, hipStream_t s)
+{
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<T>);
+    auto kern = fft_c2r_kernel<T, N, NT, R0, R1, R2, R3, TW>;
+    static dspmi::PerDeviceOnce attr;
+    if (lds > 48 * 1024 && attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    if (batch == 0) return DSPMI_OK;
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    size_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 2048 / BT) per_cu = 2048 / BT;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = (size_t)num_cu * per_cu;
+    if (grid > nfb) grid = nfb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), static_cast<C<T> *>(out),
+                       static_cast<const C<T> *>(tw), static_cast<const C<T> *>(tw2n), batch);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
 typedef dspmi::FftKernel FftEntry;
 
 // f32: twiddles in a per-workgroup LDS table (registers stay free for the butterflies: 4 waves
 // per SIMD instead of 2); f64: twiddles read from the global table through L1.
 #define F32(N, NT, A, B, C_, D)                                                                             \
     {N, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 3>, \
-     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D, launch_r2c<float, N, NT, A, B, C_, D, 2>}
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D, launch_r2c<float, N, NT, A, B, C_, D, 2>, \
+     launch_c2r<float, N, NT, A, B, C_, D, 2>}
+// short frames (fewer than 8 lanes each): no fused real-input / real-output kernels -- those
+// touch memory in pieces of 64 bytes or less there, and the complex kernel (which moves short
+// frames as contiguous runs) followed by a split / merge kernel is several times faster
+#define F32S(N, NT, A, B, C_, D)                                                                            \
+    {N, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 3>, \
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr, nullptr}
 // same, with the next frame's global loads issued before the current frame is computed
 // (frames that span several waves keep few frames in flight per CU otherwise)
 #define F32P(N, NT, A, B, C_, D)                                                                          \
     {N, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 3>, \
-     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D "_pf", launch_r2c<float, N, NT, A, B, C_, D, 2>}
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D "_pf", launch_r2c<float, N, NT, A, B, C_, D, 2>, \
+     launch_c2r<float, N, NT, A, B, C_, D, 2>}
 #define F64(N, NT, A, B, C_, D)                                                                               \
     {N, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, \
-     "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr}
+     "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr, nullptr}
 
 const FftEntry kF32[] = {
-    F32(2, 1, 2, 1, 1, 1),          F32(4, 1, 4, 1, 1, 1),          F32(8, 1, 8, 1, 1, 1),
-    F32(16, 1, 16, 1, 1, 1),        F32(32, 2, 16, 2, 1, 1),        F32(64, 4, 16, 4, 1, 1),
+    F32S(2, 1, 2, 1, 1, 1),         F32S(4, 1, 4, 1, 1, 1),         F32S(8, 1, 8, 1, 1, 1),
+    F32S(16, 1, 16, 1, 1, 1),       F32S(32, 2, 16, 2, 1, 1),       F32S(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
     F32P(1024, 64, 16, 16, 4, 1),   F32P(2048, 128, 16, 16, 8, 1),   F32P(4096, 256, 16, 16, 16, 1),
     F32P(8192, 512, 16, 16, 16, 2),
     // 16384 points fill the LDS with the frame alone: twiddles come from the global table
     {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 3>,
-     "fft_f32_n16384_r16x16x16x4", nullptr},
+     "fft_f32_n16384_r16x16x16x4", nullptr, nullptr},
 };
 const FftEntry kF64[] = {
     F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),
@@ -892,9 +1009,9 @@ const FftEntry kF64[] = {
 
 // alternative kernels for A/B runs: DSPMI_FFT_VARIANT=<index>
 const FftEntry kF32Alt1024[] = {
-    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, "fft_f32_n1024_r16x16x4_twreg", nullptr},
-    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, false, 3>, "fft_f32_n1024_r16x16x4_twlds_nopf", nullptr},
-    {1024, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false, 3>, "fft_f32_n1024_r16x8x8_twlds", nullptr},
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, "fft_f32_n1024_r16x16x4_twreg", nullptr, nullptr},
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, false, 3>, "fft_f32_n1024_r16x16x4_twlds_nopf", nullptr, nullptr},
+    {1024, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false, 3>, "fft_f32_n1024_r16x8x8_twlds", nullptr, nullptr},
 };
 
 const FftEntry *find_entry(unsigned n, int precision)

@@ -146,7 +146,8 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
 
 /* Real-input forward transform: in [batch][n] reals, out [batch][n/2+1]
  * complex (bins 0..n/2), the fftw_plan_dft_r2c_1d contract
- * (fft/src/main.c:155-158).  n must be even. */
+ * (fft/src/main.c:155-158).  Even n with a power-of-two half runs the fused real-input
+ * kernel; any other n goes through the complex transform. */
 int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                        void *stream);
 
@@ -159,7 +160,9 @@ int dspmi_fft_exec_filter(dspmi_fft_t plan, const void *in, void *out, const voi
 
 /* Backward transform of a Hermitian half spectrum: in [batch][n/2+1] complex,
  * out [batch][n] reals, unnormalised (fftw_plan_dft_c2r_1d,
- * util/filter/filter.c:100-101).  The input is left intact. */
+ * util/filter/filter.c:100-101).  The input is left intact unless the output
+ * buffer overlaps it (allowed; f32 frames then take a slower two-kernel route).
+ * The imaginary parts of bins 0 and n/2 are ignored, as FFTW ignores them. */
 int dspmi_fft_exec_c2r(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                        void *stream);
 

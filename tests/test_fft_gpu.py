@@ -143,6 +143,30 @@ def test_r2c_c2r_f32(n):
         assert rel_l2(back[f] * n, want) <= TOL_FFT
 
 
+@pytest.mark.parametrize("n,batch", [(2, 3), (4, 70), (8, 5), (32, 257), (128, 33), (2048, 37), (16384, 3)])
+def test_c2r_f32_against_oracle(n, batch):
+    """Arbitrary bins (not the transform of a real frame): the imaginary parts of bins 0 and n/2
+    are ignored, as fftw's c2r does (util/filter/filter.c:98-103); ragged batches."""
+    rng = np.random.default_rng(n + batch)
+    bins = (rng.uniform(-1, 1, (batch, n // 2 + 1)) + 1j * rng.uniform(-1, 1, (batch, n // 2 + 1))).astype(np.complex64)
+    plan = dsp_amd.FftPlan(n, "f32")
+    bd = torch.from_numpy(bins).cuda()
+    keep = bd.clone()
+    got = plan.c2r(bd).cpu().numpy()
+    assert torch.equal(bd, keep)                          # the input is left alone
+    assert got.shape == (batch, n)
+    for f in sorted({0, 1, batch // 2, batch - 1}):
+        want = oracle.fft_c2r(bins[f].astype(np.complex128), n)
+        assert rel_l2(got[f], want) <= TOL_FFT, (f, rel_l2(got[f], want))
+    # output over the input buffer (frames of bins are longer than frames of samples)
+    flat = torch.zeros(batch * (n // 2 + 1) * 2, dtype=torch.float32, device="cuda")
+    src = torch.view_as_complex(flat.view(batch, n // 2 + 1, 2))
+    src.copy_(bd)
+    out = flat[: batch * n].view(batch, n)
+    plan.c2r(src, out=out)
+    assert rel_l2(out.cpu().numpy(), got) <= 1e-6
+
+
 def test_double_wrappers(golden_dir):
     g = np.load(os.path.join(golden_dir, "fft_cases.npz"))
     x = g["filter_x"]
