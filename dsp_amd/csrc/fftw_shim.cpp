@@ -1,7 +1,8 @@
 // The FFTW3 subset the reference calls (include/dspmi_fftw3.h) over the device transforms.
 // A plan mirrors fftw_plan: it remembers the host arrays it was created for
 // (fftc/main.c:33: plan, execute, destroy per call; alsa/main.c:425-426,471: one plan
-// executed every period) and owns its device buffers, so execute allocates nothing.
+// executed every period) and owns its device buffers; the transform's own scratch is
+// allocated by the first execute and kept, so later executes allocate nothing.
 #include "common.h"
 
 #include "../../include/dspmi_fftw3.h"
