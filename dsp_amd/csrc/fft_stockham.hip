@@ -554,12 +554,14 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
             float part = 0.f;
 #pragma unroll
             for (int i = 0; i < H; i++) {
-                mlo[i] = sqrtf((float)(xlo[i].re * xlo[i].re + xlo[i].im * xlo[i].im));
-                mhi[i] = sqrtf((float)(xhi[i].re * xhi[i].re + xhi[i].im * xhi[i].im));
+                // the hardware square root (1 ulp): the library routine's extra steps would make
+                // this epilogue cost more vector instructions than the transform itself
+                mlo[i] = __builtin_amdgcn_sqrtf((float)(xlo[i].re * xlo[i].re + xlo[i].im * xlo[i].im));
+                mhi[i] = __builtin_amdgcn_sqrtf((float)(xhi[i].re * xhi[i].re + xhi[i].im * xhi[i].im));
                 // bin N (the partner of bin 0) belongs to the spectrum only when nbin = N + 1
                 part += mlo[i] + ((i == 0 && tl == 0 && nbin <= N) ? 0.f : mhi[i]);
             }
-            const float mmid = sqrtf((float)(xmid.re * xmid.re + xmid.im * xmid.im));
+            const float mmid = __builtin_amdgcn_sqrtf((float)(xmid.re * xmid.re + xmid.im * xmid.im));
             if (tl == 0) part += mmid;
             float div = 1.f, mul = 1.f;
             if (mode == 2) {
@@ -569,15 +571,18 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
                 const float sum = frame_sum<NT>(part, scratch, slot, tl);
                 if (mode == 1 || sum > 0.00001f) div = sum;
             }
+            // one reciprocal per frame instead of a division per bin (2-3 ulp in all, against a
+            // tolerance of 1e-5); a zero sum in mode 1 still yields inf / nan as a division would
+            const float gain = mul * __builtin_amdgcn_rcpf(div);
             float *dst = static_cast<float *>(out_raw) + frame * nbin;
             if (active) {
 #pragma unroll
                 for (int i = 0; i < H; i++) {
                     const unsigned k = te + NT * i;
-                    __builtin_nontemporal_store((mul * mlo[i]) / div, &dst[k]);
-                    if (N - k < nbin) __builtin_nontemporal_store((mul * mhi[i]) / div, &dst[N - k]);
+                    __builtin_nontemporal_store(mlo[i] * gain, &dst[k]);
+                    if (N - k < nbin) __builtin_nontemporal_store(mhi[i] * gain, &dst[N - k]);
                 }
-                if (tl == 0) dst[N / 2] = (mul * mmid) / div;
+                if (tl == 0) dst[N / 2] = mmid * gain;
             }
         }
     }
