@@ -27,6 +27,24 @@ inline int check_device(int plan_device, const char *what)
     return DSPMI_OK;
 }
 
+// Whether any input row [x + i*x_stride, +nx) shares an element with any output row
+// [y + j*y_stride, +ny) -- sizes and strides in elements of `esz` bytes.  Workgroups read the
+// samples before their own tile (the filter's reach), which another workgroup may already have
+// overwritten, so filtering in place is a race.  Rows interleaved in one buffer with a common
+// stride are told apart exactly; with different strides the whole spans are compared.
+inline bool rows_overlap(const void *x, size_t x_stride, size_t nx, const void *y, size_t y_stride, size_t ny, size_t nrow,
+                         size_t esz)
+{
+    if (!x || !y || nx == 0 || ny == 0 || nrow == 0) return false;
+    const char *a = static_cast<const char *>(x), *b = static_cast<const char *>(y);
+    const size_t span_a = ((nrow - 1) * x_stride + nx) * esz, span_b = ((nrow - 1) * y_stride + ny) * esz;
+    if (a + span_a <= b || b + span_b <= a) return false;
+    if (x_stride != y_stride || nrow == 1) return true;
+    const size_t row = x_stride * esz;
+    const size_t r = b >= a ? (size_t)(b - a) % row : (row - (size_t)(a - b) % row) % row;  // (y - x) mod row
+    return r < nx * esz || r + ny * esz > row;
+}
+
 // Kernel attributes (the dynamic-LDS limit) are per device: a launcher keeps one of these per
 // kernel and sets the attribute the first time it runs on each device.  Two threads may both
 // find the bit clear and both set the attribute -- harmless; the bit is set only afterwards, so

@@ -609,6 +609,8 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     if (!y || (!x && nx)) return dspmi::fail(DSPMI_EINVAL, "fir_exec: null buffer");
     if (y_stride < nxx || x_stride < nx) return dspmi::fail(DSPMI_EINVAL, "fir_exec: stride smaller than the row length");
     if (hist && hist_stride + 1 < pl->nh) return dspmi::fail(DSPMI_EINVAL, "fir_exec: hist_stride < nh-1");
+    if (dspmi::rows_overlap(x, x_stride, nx, y, y_stride, nxx, nchan, sizeof(T)))
+        return dspmi::fail(DSPMI_EINVAL, "fir_exec: input and output rows overlap (filtering in place is not supported)");
     FirParams<T> p;
     p.y = y; p.x = x; p.hist = hist; p.taps = static_cast<const T *>(pl->taps_dev);
     p.y_stride = y_stride; p.x_stride = x_stride; p.hist_stride = hist_stride;

@@ -182,6 +182,8 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
     if (!x || !y) return dspmi::fail(DSPMI_EINVAL, "ols_exec: null buffer");
     if (x_stride < nx || y_stride < nx) return dspmi::fail(DSPMI_EINVAL, "ols_exec: stride smaller than the row length");
     if (hist && hist_stride + 1 < plan->nh) return dspmi::fail(DSPMI_EINVAL, "ols_exec: hist_stride < nh-1");
+    if (plan->nh > 1 && dspmi::rows_overlap(x, x_stride, nx, y, y_stride, nx, nchan, sizeof(float)))
+        return dspmi::fail(DSPMI_EINVAL, "ols_exec: input and output rows overlap (filtering in place is not supported)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (plan->fused) {
         dspmi::OlsLaunch o;

@@ -86,7 +86,9 @@ int dspmi_fir_destroy(dspmi_fir_t plan);
  * reference lacks (alsa/main.c:530 restarts from zero every period).
  *
  * x, y, hist: DEVICE pointers; x_stride / y_stride: elements between
- * consecutive channels (>= nx / >= nxx).  y must not overlap x.
+ * consecutive channels (>= nx / >= nxx).  No output row may share an element
+ * with an input row (DSPMI_EINVAL): workgroups read the samples before their
+ * own tile, so filtering in place would race.
  * stream: a hipStream_t (NULL = the default stream).  Asynchronous.
  */
 int dspmi_fir_exec_f32(dspmi_fir_t plan, float *y, size_t y_stride, unsigned nxx,

@@ -240,3 +240,27 @@ def test_degenerate_shapes_through_the_abi():
     assert np.array_equal(dsp_amd.conv0(np.array([2.0]), np.array([3.0])), np.array([6.0]))
     assert np.array_equal(dsp_amd.conv1(np.array([2.0]), np.array([3.0])), np.array([0.0]))
     assert np.array_equal(dsp_amd.convolve(np.array([1.0, 2.0]), np.array([1.0]), 5), np.array([1.0, 2.0, 0, 0, 0]))
+
+
+def test_in_place_is_refused_interleaved_rows_are_not(fir_path):
+    """A tile reads the nh-1 samples before it, which another workgroup may already have
+    replaced: output rows that touch input rows are an argument error, for both kernels.  Rows
+    of x and y interleaved in one buffer (common stride, disjoint columns) are fine."""
+    rng = np.random.default_rng(11)
+    h = oracle.windowed_sinc_taps(127).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    nchan, nx = 3, 6000
+    buf = torch.zeros((nchan, 2 * nx + 64), device="cuda")
+    x = buf[:, :nx]
+    x.copy_(torch.from_numpy(rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)))
+    with pytest.raises(dsp_amd.DspmiError, match="overlap"):
+        plan.exec(x, y=x)
+    with pytest.raises(dsp_amd.DspmiError, match="overlap"):
+        plan.exec(x, y=buf[:, nx - 1:2 * nx - 1])          # one shared column
+    y = plan.exec(x, nx + 64, y=buf[:, nx:])               # interleaved, disjoint, filling the row exactly
+    want = oracle.fir_batch_f32(x.cpu().numpy(), h, nx + 64)
+    for c in range(nchan):
+        assert rel_l2(y[c].cpu().numpy(), want[c]) <= TOL_FIR
+    y = plan.exec(x, y=buf[:, nx:2 * nx])
+    for c in range(nchan):
+        assert rel_l2(y[c].cpu().numpy(), want[c, :nx]) <= TOL_FIR
