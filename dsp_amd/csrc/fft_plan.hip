@@ -367,6 +367,12 @@ bool fused_real(const dspmi_fft_plan *pl)
     return pl->kern_half && pl->kern_half->fn_r2c && pl->kern_half->fn_c2r && !getenv("DSPMI_FFT_REAL_COMPOSED");
 }
 
+bool ranges_overlap(const void *a, size_t a_bytes, const void *b, size_t b_bytes)
+{
+    const char *p = static_cast<const char *>(a), *q = static_cast<const char *>(b);
+    return p < q + b_bytes && q < p + a_bytes;
+}
+
 template <typename T>
 int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipStream_t s)
 {
@@ -377,7 +383,10 @@ int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
-    if (fused_real(pl))  // transform + split in one kernel
+    // transform + split in one kernel -- unless the output overlaps the input: frames of samples
+    // and frames of bins have different lengths, so workgroups would overwrite each other's
+    // input.  That case takes the two-kernel route below, which reads everything first.
+    if (fused_real(pl) && !ranges_overlap(in, batch * (size_t)n * sizeof(T), out, batch * (size_t)(n / 2 + 1) * sizeof(C<T>)))
         return pl->kern_half->fn_r2c(in, out, pl->tw_half, pl->tw_n, batch, 1, n / 2 + 1, 0, 0.f, pl->num_cu, s);
     if (pl->kern_half) {
         int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
@@ -421,9 +430,7 @@ int c2r_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
         // merge + transform in one kernel.  Frames of bins and frames of samples have
         // different lengths, so workgroups would trample each other's input in an overlapping
         // buffer: that case takes the two-kernel route below.
-        const char *a = static_cast<const char *>(in), *b = static_cast<const char *>(out);
-        const size_t in_bytes = batch * (size_t)(n / 2 + 1) * sizeof(C<T>), out_bytes = batch * (size_t)n * sizeof(T);
-        if (a + in_bytes <= b || b + out_bytes <= a)
+        if (!ranges_overlap(in, batch * (size_t)(n / 2 + 1) * sizeof(C<T>), out, batch * (size_t)n * sizeof(T)))
             return pl->kern_half->fn_c2r(in, out, pl->tw_half, pl->tw_n, batch, pl->num_cu, s);
     }
     if (pl->kern_half) {
@@ -596,6 +603,10 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
     if (sign != DSPMI_FORWARD && sign != DSPMI_BACKWARD) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: sign must be -1 or +1");
     if (batch == 0) return DSPMI_OK;
     if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: null buffer");
+    // frames are transformed whole (loaded, then stored), so in place is fine; a shifted overlap
+    // would let one workgroup overwrite another's input
+    if (in != out && ranges_overlap(in, batch * (size_t)plan->n * plan->esz, out, batch * (size_t)plan->n * plan->esz))
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c: in and out overlap without being the same buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (plan->n == 1) {
         if (in != out) DSPMI_HIP(hipMemcpyAsync(out, in, batch * plan->esz, hipMemcpyDeviceToDevice, s));
@@ -637,6 +648,8 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
     if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: mode must be 0, 1 or 2");
     const unsigned n = plan->n;
     if (nbin == 0 || nbin > n / 2 + 1) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: nbin must be 1..n/2+1");
+    if (ranges_overlap(in, batch * (size_t)n * sizeof(float), ps, batch * (size_t)nbin * sizeof(float)))
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum: the spectrum buffer overlaps the input");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (fused_real(plan) && nbin >= n / 2)
         return plan->kern_half->fn_r2c(in, ps, plan->tw_half, plan->tw_n, batch, 2, nbin, mode, scale, plan->num_cu, s);
@@ -661,6 +674,8 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
     if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: mode must be 0, 1 or 2");
     const unsigned n = plan->n;
     if (nbin == 0 || nbin > n / 2 + 1) return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: nbin must be 1..n/2+1");
+    if (ranges_overlap(in, batch * (size_t)n * 2 * sizeof(int16_t), ps, batch * (size_t)nbin * sizeof(float)))
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_r2c_spectrum_s16x2: the spectrum buffer overlaps the input");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (fused_real(plan) && nbin >= n / 2)
         return plan->kern_half->fn_r2c(in, ps, plan->tw_half, plan->tw_n, batch, 2 | dspmi::kR2cSourceS16x2, nbin, mode, scale,

@@ -142,14 +142,16 @@ int dspmi_fft_destroy(dspmi_fft_t plan);
 
 /* batch independent transforms, frame f at in + f*n / out + f*n (elements of
  * dspmi_c32 or dspmi_c64 according to the plan's precision).  Unnormalised in
- * both directions, natural order in and out.  in == out is allowed. */
+ * both directions, natural order in and out.  in == out is allowed; buffers that
+ * overlap without being the same are refused (DSPMI_EINVAL). */
 int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                        int sign, void *stream);
 
 /* Real-input forward transform: in [batch][n] reals, out [batch][n/2+1]
  * complex (bins 0..n/2), the fftw_plan_dft_r2c_1d contract
  * (fft/src/main.c:155-158).  Even n with a power-of-two half runs the fused real-input
- * kernel; any other n goes through the complex transform. */
+ * kernel; any other n goes through the complex transform.  out may overlap in
+ * (a slower two-kernel route that reads everything first). */
 int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                        void *stream);
 

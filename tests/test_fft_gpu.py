@@ -167,6 +167,27 @@ def test_c2r_f32_against_oracle(n, batch):
     assert rel_l2(out.cpu().numpy(), got) <= 1e-6
 
 
+@pytest.mark.parametrize("n", [64, 2048])
+def test_r2c_over_its_own_input_and_shifted_c2c(n):
+    """Bins written over the samples they come from (frames of bins are longer than frames of
+    samples, so this cannot run as one kernel); a c2c whose output is the input shifted by a
+    frame is an argument error."""
+    rng = np.random.default_rng(n)
+    batch, nb = 9, n // 2 + 1
+    x = rng.uniform(-1, 1, (batch, n)).astype(np.float32)
+    plan = dsp_amd.FftPlan(n, "f32")
+    want = plan.r2c(torch.from_numpy(x).cuda()).cpu().numpy()
+    flat = torch.zeros(batch * nb * 2, dtype=torch.float32, device="cuda")
+    src = flat[: batch * n].view(batch, n)
+    src.copy_(torch.from_numpy(x))
+    out = torch.view_as_complex(flat.view(batch, nb, 2))
+    plan.r2c(src, out=out)
+    assert rel_l2(out.cpu().numpy(), want) <= 1e-6
+    z = torch.view_as_complex(torch.rand(batch + 1, n, 2, device="cuda"))
+    with pytest.raises(dsp_amd.DspmiError, match="overlap"):
+        plan.c2c(z[:batch], out=z[1:])
+
+
 def test_double_wrappers(golden_dir):
     g = np.load(os.path.join(golden_dir, "fft_cases.npz"))
     x = g["filter_x"]
