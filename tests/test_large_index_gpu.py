@@ -1,0 +1,57 @@
+"""Rows and batches whose element and byte offsets pass 2^31 and 2^32: one channel of
+2^31 + 5000 samples through both FIR kernels, and a c2c batch of more than 2^32 complex points.
+Checked on windows around the offsets where a 32-bit byte or element index would wrap."""
+import numpy as np
+import pytest
+import torch
+
+import dsp_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(got, want):
+    return float(np.linalg.norm(got - want) / np.linalg.norm(want))
+
+
+@pytest.mark.parametrize("nh,path", [(16, "direct"), (127, "overlap_save"), (127, "direct")])
+def test_fir_row_longer_than_2_31_samples(nh, path, monkeypatch):
+    if torch.cuda.mem_get_info()[0] < 40 << 30:
+        pytest.skip("needs 40 GiB of free device memory")
+    if path == "direct":
+        monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")
+    nx = (1 << 31) + 5000
+    h = (np.asarray(oracle.TAPS16) if nh == 16 else oracle.windowed_sinc_taps(nh)).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert ("overlap_save" in plan.variant) == (path == "overlap_save")
+    g = torch.Generator(device="cuda").manual_seed(nh)
+    x = torch.rand((1, nx), device="cuda", generator=g) * 2 - 1
+    y = plan.exec(x)
+    torch.cuda.synchronize()
+    width = 6000
+    for s in (0, (1 << 29) - 3000, (1 << 30) - 3000, (1 << 31) - 3000, nx - width):
+        lo = max(0, s - (nh - 1))
+        win = x[0, lo:s + width].cpu().numpy()
+        want = oracle.fir_batch_f32(win[None, :], h, len(win))[0][s - lo:]
+        got = y[0, s:s + width].cpu().numpy()
+        assert rel_l2(got, want) <= 1e-6, (s, rel_l2(got, want))
+    del x, y
+    torch.cuda.empty_cache()
+
+
+def test_c2c_batch_of_more_than_2_32_points():
+    if torch.cuda.mem_get_info()[0] < 80 << 30:
+        pytest.skip("needs 80 GiB of free device memory")
+    n = 1024
+    batch = (1 << 22) + 3                     # 2^32 + 3072 complex points, 32 GiB each way
+    g = torch.Generator(device="cuda").manual_seed(1)
+    z = torch.view_as_complex(torch.rand((batch, n, 2), device="cuda", generator=g) * 2 - 1)
+    plan = dsp_amd.FftPlan(n, "f32")
+    out = plan.c2c(z)
+    torch.cuda.synchronize()
+    for f in (0, (1 << 18) - 1, 1 << 18, (1 << 21), (1 << 22) - 1, 1 << 22, batch - 1):
+        want = oracle.dft(z[f].cpu().numpy().astype(np.complex128), -1, "direct")
+        assert rel_l2(out[f].cpu().numpy(), want) <= 1e-5, (f, rel_l2(out[f].cpu().numpy(), want))
+    del z, out
+    torch.cuda.empty_cache()
