@@ -21,6 +21,14 @@
  *     reference's unprefixed names (conv0, convolve, fir, dft, ...) onto them.
  *
  * No C++ or torch types appear in any signature.
+ *
+ * Threads: any number of threads may create, execute and destroy DIFFERENT plans
+ * concurrently.  One plan must not be executed from two threads (or on two
+ * streams) at once: FFT and overlap-save plans own scratch buffers that an
+ * execute may grow and that consecutive kernels of one execute share.  FIR
+ * plans hold only the taps and may be shared freely.  Every execute is
+ * asynchronous on the stream given; destroying a plan while its work is still
+ * queued is the caller's error, as with fftw_destroy_plan.
  */
 #ifndef DSPMI_H_INCLUDED
 #define DSPMI_H_INCLUDED
