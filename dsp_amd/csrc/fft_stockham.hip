@@ -153,11 +153,12 @@ __device__ __forceinline__ void frame_sync()
 // The lane index as the transform passes see it.  With twiddles read from the global table
 // (TW == 0) every twiddle load has a loop-invariant address, and the compiler hoists all of them
 // out of the frame loop -- hundreds of registers, spilled to scratch.  Passing the index through
-// an empty asm once per frame makes the loads per-frame again (they hit L1 / L2).
+// an empty asm once per frame makes the loads per-frame again (they hit L1 / L2).  The split
+// tables (TW == 3) have the same problem with their index arithmetic.
 template <int TW>
 __device__ __forceinline__ unsigned pass_lane(unsigned tl)
 {
-    if constexpr (TW == 0) asm volatile("" : "+v"(tl));
+    if constexpr (TW == 0 || TW == 3) asm volatile("" : "+v"(tl));
     return tl;
 }
 
@@ -185,7 +186,9 @@ __device__ __forceinline__ void load_twiddles(C<T> *twr, const C<T> *__restrict_
 //   FIRST: sources are v as loaded from global by the caller; otherwise read from LDS
 //   LAST : results stay in v (caller stores to global); otherwise written to LDS
 // Twiddle source (TW): 0 = the global table (through L1), 1 = registers filled once per
-// lane (twr), 2 = a per-workgroup LDS table laid out [r-1][j mod NS] (twr points at it).
+// lane (twr), 2 = a per-workgroup LDS table laid out [r-1][j mod NS] (twr points at it),
+// 3 = that table for passes with NS <= 16 and, for the others, two short LDS tables
+// A[a] = W^(64a), B[b] = W^b whose product is the twiddle (twr points at A, B follows).
 template <typename T, int N, int NT, int R, int NS, bool FIRST, bool LAST, int TW>
 __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
 {
@@ -206,8 +209,12 @@ __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, co
             for (int r = 1; r < R; r++) {
                 C<T> w;
                 if constexpr (TW == 1) w = twr[b * (R - 1) + r - 1];
-                else if constexpr (TW == 2) w = twr[(r - 1) * NS + k];
-                else w = tw[k * r * (N / (NS * R))];
+                else if constexpr (TW == 2 || (TW == 3 && NS <= 16)) w = twr[(r - 1) * NS + k];
+                else if constexpr (TW == 3) {
+                    // W^e, e = 64*a + b, as the product of two short tables
+                    const unsigned e = k * (r * (N / (NS * R)));
+                    w = cmul(twr[e >> 6], twr[N / 64 + (e & 63)]);
+                } else w = tw[k * r * (N / (NS * R))];
                 v[b * R + r] = cmul(v[b * R + r], w);
             }
         }
@@ -247,11 +254,33 @@ __device__ __forceinline__ void setup_lds_twiddles(char *smem_raw, const C<T> *_
     tw3 = t3;
 }
 
-constexpr size_t lds_twiddle_entries(int TW, int R0, int R1, int R2, int R3)
+// Long frames: full tables hold about N entries whatever the radix order, as much LDS as the
+// frame itself.  Only the first twiddled pass (NS = R0 <= 16) keeps its table; the other passes
+// build W^e from A[e >> 6] * B[e & 63], N/64 + 64 entries in all, at the price of one complex
+// multiplication per twiddle.  Ends with a barrier.
+template <typename T, int N, int BT, int FPB, int R0, int R1>
+__device__ __forceinline__ void setup_lds_twiddles_split(char *smem_raw, const C<T> *__restrict__ tw, const C<T> *&tw1,
+                                                         const C<T> *&tw2, const C<T> *&tw3)
 {
-    return TW == 2 ? (size_t)(R1 > 1 ? (R1 - 1) * R0 : 0) + (R2 > 1 ? (R2 - 1) * R0 * R1 : 0) +
+    static_assert(R0 <= 16 && N % 64 == 0, "first pass table only for NS <= 16");
+    C<T> *t1 = reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N);
+    C<T> *ta = t1 + (R1 > 1 ? (R1 - 1) * R0 : 0);
+    if constexpr (R1 > 1)
+        for (unsigned i = threadIdx.x; i < (R1 - 1) * R0; i += BT) t1[i] = tw[(i % R0) * (i / R0 + 1) * (N / (R0 * R1))];
+    for (unsigned i = threadIdx.x; i < N / 64; i += BT) ta[i] = tw[64 * i];
+    for (unsigned i = threadIdx.x; i < 64; i += BT) ta[N / 64 + i] = tw[i];
+    __syncthreads();
+    tw1 = t1;
+    tw2 = ta;
+    tw3 = ta;
+}
+
+constexpr size_t lds_twiddle_entries(int TW, int R0, int R1, int R2, int R3, int N = 0)
+{
+    return TW == 2   ? (size_t)(R1 > 1 ? (R1 - 1) * R0 : 0) + (R2 > 1 ? (R2 - 1) * R0 * R1 : 0) +
                          (R3 > 1 ? (R3 - 1) * R0 * R1 * R2 : 0)
-                   : 0;
+           : TW == 3 ? (size_t)(R1 > 1 ? (R1 - 1) * R0 : 0) + N / 64 + 64
+                     : 0;
 }
 
 // All passes of one frame: v holds the first pass's inputs on entry and the last pass's
@@ -305,6 +334,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
         load_twiddles<T, N, NT, R3, NS3>(tw3r, tw, tl);
     }
     if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    if constexpr (TW == 3) setup_lds_twiddles_split<T, N, BT, FPB, R0, R1>(smem_raw, tw, tw1, tw2, tw3);
     const T sgn = backward ? T(-1) : T(1);
 
     const size_t nfb = (batch + FPB - 1) / FPB;
@@ -474,10 +504,11 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
     const unsigned tl = threadIdx.x % NT;
     C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
     float *scratch = reinterpret_cast<float *>(reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N) +
-                                               lds_twiddle_entries(TW, R0, R1, R2, R3));
+                                               lds_twiddle_entries(TW, R0, R1, R2, R3, N));
 
     const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
     if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    if constexpr (TW == 3) setup_lds_twiddles_split<T, N, BT, FPB, R0, R1>(smem_raw, tw, tw1, tw2, tw3);
 
     const size_t nfb = (batch + FPB - 1) / FPB;
     for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
@@ -618,6 +649,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2r_kernel(const C<T>
     C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
     const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
     if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    if constexpr (TW == 3) setup_lds_twiddles_split<T, N, BT, FPB, R0, R1>(smem_raw, tw, tw1, tw2, tw3);
 
     const size_t nfb = (batch + FPB - 1) / FPB;
     for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
@@ -707,6 +739,7 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
     C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
     const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
     if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    if constexpr (TW == 3) setup_lds_twiddles_split<T, N, BT, FPB, R0, R1>(smem_raw, tw, tw1, tw2, tw3);
 
     const long nx = a.nx, nh = a.nh, L = a.L;
     const size_t total = (size_t)a.nchan * a.npair;
@@ -823,7 +856,7 @@ int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_
 {
     constexpr int BT = ols_block_threads<N, NT>();
     constexpr int FPB = BT / NT;
-    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<float>);
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3, N)) * sizeof(C<float>);
     auto kern = ols_fused_kernel<N, NT, R0, R1, R2, R3, TW>;
     static dspmi::PerDeviceOnce attr;
     if (lds > 48 * 1024 && attr.pending()) {
@@ -858,8 +891,8 @@ struct OlsEntry {
 const OlsEntry kOls[] = {
     OLS(16, 1, 16, 1, 1, 1, 0),        OLS(32, 2, 4, 2, 4, 1, 2),          OLS(64, 4, 4, 4, 4, 1, 2),
     OLS(128, 8, 4, 8, 4, 1, 2),        OLS(256, 16, 16, 16, 1, 1, 2),      OLS(512, 32, 16, 2, 16, 1, 2),
-    OLS(1024, 64, 16, 4, 16, 1, 2),    OLS(2048, 128, 16, 8, 16, 1, 2),    OLS(4096, 256, 16, 16, 16, 1, 2),
-    OLS(8192, 512, 16, 16, 2, 16, 2),  OLS(16384, 512, 16, 16, 4, 16, 0),
+    OLS(1024, 64, 16, 4, 16, 1, 2),    OLS(2048, 128, 16, 8, 16, 1, 2),    OLS(4096, 256, 16, 16, 16, 1, 3),
+    OLS(8192, 512, 16, 16, 2, 16, 3),  OLS(16384, 512, 16, 16, 4, 16, 3),
 };
 
 // ---------------------------------------------------------------------------
@@ -872,7 +905,7 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     constexpr int BT = block_threads<NT>();
     constexpr int FPB = BT / NT;
     constexpr bool single_pass = R1 == 1 && R2 == 1 && R3 == 1;  // global -> registers -> global
-    constexpr size_t tw_entries = lds_twiddle_entries(TW, R0, R1, R2, R3);
+    constexpr size_t tw_entries = lds_twiddle_entries(TW, R0, R1, R2, R3, N);
     constexpr bool staged = NT < 16;  // short frames move through their LDS images (see the kernel)
     constexpr size_t lds = (single_pass && !staged) ? 0 : ((size_t)FPB * padded_len(N) + tw_entries) * sizeof(C<T>);
     auto kern = fft_c2c_kernel<T, N, NT, R0, R1, R2, R3, TW, PREFETCH, NTMEM>;
@@ -920,7 +953,7 @@ int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size
 {
     constexpr int BT = block_threads<NT>();
     constexpr int FPB = BT / NT;
-    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<T>) +
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3, N)) * sizeof(C<T>) +
                            (size_t)FPB * (NT > 64 ? NT / 64 : 1) * sizeof(float);
     auto k1 = fft_r2c_kernel<T, N, NT, R0, R1, R2, R3, TW, 1>;
     auto k2 = fft_r2c_kernel<T, N, NT, R0, R1, R2, R3, TW, 2>;
@@ -950,7 +983,7 @@ int launch_c2r(const void *in, void *out, const void *tw, const void *tw2n, size
 {
     constexpr int BT = block_threads<NT>();
     constexpr int FPB = BT / NT;
-    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3)) * sizeof(C<T>);
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3, N)) * sizeof(C<T>);
     auto kern = fft_c2r_kernel<T, N, NT, R0, R1, R2, R3, TW>;
     static dspmi::PerDeviceOnce attr;
     if (lds > 48 * 1024 && attr.pending()) {
@@ -990,6 +1023,14 @@ typedef dspmi::FftKernel FftEntry;
     {N, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 3>, \
      "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D "_pf", launch_r2c<float, N, NT, A, B, C_, D, 2>, \
      launch_c2r<float, N, NT, A, B, C_, D, 2>}
+// long frames: full twiddle tables hold about N entries whatever the radix order -- as much LDS
+// as the frame itself -- so the complex kernel builds its twiddles from two short tables and
+// twice as many workgroups fit a CU (4096: 4.7 -> 5.2 TB/s, 8192: 3.6 -> 5.1, 16384: 2.8 -> 3.8).
+// TWR is the table kind of the real-input / real-output kernels (split pays there from 8192 on).
+#define F32T(N, NT, A, B, C_, D, TWR)                                                                       \
+    {N, launch_c2c<float, N, NT, A, B, C_, D, 3, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 3, false, 3>, \
+     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D "_splittw", launch_r2c<float, N, NT, A, B, C_, D, TWR>,     \
+     launch_c2r<float, N, NT, A, B, C_, D, TWR>}
 #define F64(N, NT, A, B, C_, D)                                                                               \
     {N, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, \
      "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr, nullptr}
@@ -998,11 +1039,10 @@ const FftEntry kF32[] = {
     F32S(2, 1, 2, 1, 1, 1),         F32S(4, 1, 4, 1, 1, 1),         F32S(8, 1, 8, 1, 1, 1),
     F32S(16, 1, 16, 1, 1, 1),       F32S(32, 2, 16, 2, 1, 1),       F32S(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
-    F32P(1024, 64, 16, 16, 4, 1),   F32P(2048, 128, 16, 16, 8, 1),   F32P(4096, 256, 16, 16, 16, 1),
-    F32P(8192, 512, 16, 16, 16, 2),
-    // 16384 points fill the LDS with the frame alone: twiddles come from the global table
-    {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 0, false, 3>,
-     "fft_f32_n16384_r16x16x16x4", nullptr, nullptr},
+    F32P(1024, 64, 16, 16, 4, 1),   F32P(2048, 128, 16, 16, 8, 1),   F32T(4096, 256, 16, 16, 16, 1, 2),
+    F32T(8192, 512, 16, 16, 16, 2, 3),
+    {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 3>,
+     "fft_f32_n16384_r16x16x16x4_splittw", nullptr, nullptr},
 };
 const FftEntry kF64[] = {
     F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),

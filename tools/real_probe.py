@@ -9,7 +9,7 @@ import dsp_amd  # noqa: E402
 from tools.c2r_probe import timed  # noqa: E402
 
 total = 1 << 28
-for n in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096):
+for n in (8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384):
     batch = total // n
     nb = n // 2 + 1
     x = torch.rand(batch, n, device="cuda") - 0.5
