@@ -13,11 +13,13 @@
 // Input and output are in natural order, so no bit-reversal pass exists.  The
 // twiddles come from a table built in double precision on the host; the f32
 // kernels copy the entries their passes need into a per-workgroup LDS table
-// (registers stay free for the butterflies), the f64 and 16384-point kernels
-// read the global table.  When NT <= 64 a frame lives inside one wave and the
-// passes need no workgroup barrier.  Besides the plain c2c kernel the file holds
-// the fused real-input kernel (split and spectrum epilogues) and the fused
-// overlap-save kernel (forward transform, multiply, backward transform on chip).
+// (registers stay free for the butterflies; long frames keep two short tables
+// there and multiply a twiddle together from them), the f64 kernels read the
+// global table.  When NT <= 64 a frame lives inside one wave and the passes need
+// no workgroup barrier.  Besides the plain c2c kernel the file holds the fused
+// real-input kernel (split and spectrum epilogues), the fused real-output kernel
+// and the fused overlap-save kernel (forward transform, multiply, backward
+// transform on chip).
 // It is compiled without SLP vectorisation: packed f32 instructions issue at half
 // rate on gfx950, so pairing scalars only costs register moves.
 //
