@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
     ap.add_argument("--long-samples", type=int, default=1 << 26, help="samples of the single long signal (8191-tap workloads)")
+    ap.add_argument("--chunks", type=int, default=4, help="chain workload: chunks the 2^20 samples per channel are streamed in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     return ap.parse_args()
@@ -198,7 +199,7 @@ def make_chain(args, rank):
     magnitude spectrum, streamed in 4 chunks; the generator's phases and the FIR history are
     carried from chunk to chunk.  Every stage runs inside the timed step; the time of the
     FIR + FFT stages alone (tones pre-generated) is reported beside it."""
-    nchan, nfft, nchunk = 1024, 4096, 4
+    nchan, nfft, nchunk = 1024, 4096, args.chunks
     chunk = (1 << 20) // nchunk
     nh = 127
     taps = sinc_taps(nh)
