@@ -869,7 +869,7 @@ int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_
     a.x = o.x; a.hist = o.hist; a.y = o.y; a.H = static_cast<const C<float> *>(o.H);
     a.x_stride = o.x_stride; a.y_stride = o.y_stride; a.hist_stride = o.hist_stride;
     a.nx = o.nx; a.nh = o.nh; a.L = N - (o.nh - 1);
-    a.nblk = (o.nx + a.L - 1) / a.L;
+    a.nblk = (unsigned)(((unsigned long long)o.nx + a.L - 1) / a.L);
     a.npair = (a.nblk + 1) / 2;
     a.nchan = o.nchan;
     const size_t total = (size_t)a.nchan * a.npair;

@@ -501,7 +501,7 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
         const size_t want = (160 * 1024) / bpc - 512;
         if (want > lds) lds = want;
     }
-    p.tiles_per_chan = (p.nxx + TILE - 1) / TILE;
+    p.tiles_per_chan = (unsigned)(((unsigned long long)p.nxx + TILE - 1) / TILE);
     const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
     if (tiles == 0) return DSPMI_OK;
     if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
@@ -625,13 +625,13 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
             return launch_mfma(p, nchan, s);
         }
         if (pl->variant == V_F32_SHORT) {
-            p.tiles_per_chan = (nxx + 4095) / 4096;
+            p.tiles_per_chan = (unsigned)(((unsigned long long)nxx + 4095) / 4096);
             return launch<float, 4, 4, 16, false, false>(p, nchan, s);
         }
-        p.tiles_per_chan = (nxx + 4095) / 4096;
+        p.tiles_per_chan = (unsigned)(((unsigned long long)nxx + 4095) / 4096);
         return launch<float, 8, 2, 16, false, false>(p, nchan, s);
     } else {
-        p.tiles_per_chan = (nxx + 2047) / 2048;
+        p.tiles_per_chan = (unsigned)(((unsigned long long)nxx + 2047) / 2048);
         if (desc) return launch<double, 4, 2, 8, true, true>(p, nchan, s);
         return launch<double, 4, 2, 8, true, false>(p, nchan, s);
     }
@@ -711,7 +711,7 @@ int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, cons
     p.taps = static_cast<const double *>(plan->taps_dev);
     p.y_stride = out_stride; p.x_stride = in_stride; p.hist_stride = 0;
     p.nxx = nsampl; p.nx = nsampl; p.nh = plan->nh; p.nhp = plan->nhp; p.flags = 0;
-    p.tiles_per_chan = (nsampl + 2047) / 2048;
+    p.tiles_per_chan = (unsigned)(((unsigned long long)nsampl + 2047) / 2048);
     return launch<double, 4, 2, 8, true, false, true>(p, nblock, static_cast<hipStream_t>(stream));
 }
 

@@ -194,7 +194,7 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
     }
     OlsShape sh;
     sh.N = plan->N; sh.L = plan->L; sh.nh = plan->nh;
-    sh.nblk = (nx + sh.L - 1) / sh.L;
+    sh.nblk = (unsigned)(((unsigned long long)nx + sh.L - 1) / sh.L);
     sh.npair = (sh.nblk + 1) / 2;
     sh.nx = nx; sh.nchan = nchan;
     sh.x_stride = x_stride; sh.y_stride = y_stride; sh.hist_stride = hist_stride;

@@ -15,13 +15,15 @@ def rel_l2(got, want):
     return float(np.linalg.norm(got - want) / np.linalg.norm(want))
 
 
-@pytest.mark.parametrize("nh,path", [(16, "direct"), (127, "overlap_save"), (127, "direct")])
-def test_fir_row_longer_than_2_31_samples(nh, path, monkeypatch):
-    if torch.cuda.mem_get_info()[0] < 40 << 30:
-        pytest.skip("needs 40 GiB of free device memory")
+@pytest.mark.parametrize("nh,path,nx", [(16, "direct", (1 << 31) + 5000), (127, "overlap_save", (1 << 31) + 5000),
+                                        (127, "direct", (1 << 31) + 5000),
+                                        # the longest row the 32-bit sample count can express
+                                        (127, "overlap_save", (1 << 32) - 3), (16, "direct", (1 << 32) - 3)])
+def test_fir_row_longer_than_2_31_samples(nh, path, nx, monkeypatch):
+    if torch.cuda.mem_get_info()[0] < 60 << 30:
+        pytest.skip("needs 60 GiB of free device memory")
     if path == "direct":
         monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")
-    nx = (1 << 31) + 5000
     h = (np.asarray(oracle.TAPS16) if nh == 16 else oracle.windowed_sinc_taps(nh)).astype(np.float32)
     plan = dsp_amd.FirPlan(h, "f32")
     assert ("overlap_save" in plan.variant) == (path == "overlap_save")
@@ -30,7 +32,7 @@ def test_fir_row_longer_than_2_31_samples(nh, path, monkeypatch):
     y = plan.exec(x)
     torch.cuda.synchronize()
     width = 6000
-    for s in (0, (1 << 29) - 3000, (1 << 30) - 3000, (1 << 31) - 3000, nx - width):
+    for s in (0, (1 << 29) - 3000, (1 << 30) - 3000, (1 << 31) - 3000, nx - (1 << 20), nx - width):
         lo = max(0, s - (nh - 1))
         win = x[0, lo:s + width].cpu().numpy()
         want = oracle.fir_batch_f32(win[None, :], h, len(win))[0][s - lo:]
