@@ -545,6 +545,8 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
             k = dspmi::fft_find(n, precision);
             if (!k) return dspmi::fail(DSPMI_ENOSYS, "fft_create: no %s kernel for n = %u", pname, n);
         } else {
+            // the convolution length must cover 2n-1 points and fit the longest kernel
+            if (n > (1u << 20)) return dspmi::fail(DSPMI_ENOSYS, "fft_create: n = %u is not a power of two and too long", n);
             M = 1;
             while (M < 2 * n - 1) M <<= 1;
             kM = dspmi::fft_find(M, precision);

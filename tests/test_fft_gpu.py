@@ -277,3 +277,25 @@ def test_filter_one_kernel_form_matches_the_composition(n, batch, monkeypatch):
         want = oracle.filter(x[f].double().cpu().numpy(), gains.double().cpu().numpy())
         assert rel_l2(fused[f], want) <= TOL_FFT, (f, rel_l2(fused[f], want))
         assert rel_l2(composed[f], want) <= TOL_FFT
+
+
+def test_lengths_no_kernel_covers_are_refused():
+    """Plan creation answers -ENOSYS (with a message) instead of planning something it cannot run."""
+    import ctypes as C
+    L = dsp_amd.lib()
+    for n, prec in ((32768, 0), (9000, 0), ((1 << 31) - 100, 0), ((1 << 31) + 1, 0), (16384, 1), (5000, 1)):
+        h = C.c_void_p()
+        rc = L.dspmi_fft_create(C.byref(h), n, prec, -1)
+        assert rc == -38 and not h.value, (n, prec, rc)
+        assert b"fft_create" in L.dspmi_last_error()
+    h = C.c_void_p()
+    assert L.dspmi_fft_create(C.byref(h), 0, 0, -1) == -22
+    assert L.dspmi_fft_create(C.byref(h), 1024, 7, -1) == -22
+    assert L.dspmi_fft_create(None, 1024, 0, -1) == -22
+    # the longest lengths that do exist
+    for n, dtype in ((16384, "f32"), (8192, "f64"), (8191, "f32")):
+        plan = dsp_amd.FftPlan(n, dtype)
+        z = torch.view_as_complex(torch.rand(2, n, 2, device="cuda", dtype=torch.float32 if dtype == "f32" else torch.float64))
+        got = plan.c2c(z).cpu().numpy()
+        want = np.fft.fft(z.cpu().numpy().astype(np.complex128), axis=1)
+        assert rel_l2(got, want) <= (TOL_FFT if dtype == "f32" else TOL_F64)
