@@ -92,6 +92,14 @@ def lib():
         if not os.path.exists(path):
             raise DspmiError("%s not found: build it with `python -m dsp_amd.build` "
                              "(or __graft_entry__.build())" % path)
+        # This harness hands torch's device buffers to the library, so both must talk to one HIP
+        # runtime: torch brings its own copy, and whichever copy is loaded second finds no device.
+        # Importing torch first lets the library's libamdhip64 dependency resolve to the copy
+        # already in the process.  (A C program linking libdspmi.so has one runtime anyway.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

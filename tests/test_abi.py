@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 import dsp_amd
 import importlib
 
@@ -65,3 +67,17 @@ def test_fftw_subset_symbols_exported():
     p = lib.dspmi_fftw_malloc(1024)
     assert p and p % 64 == 0
     lib.dspmi_fftw_free(p)
+
+
+@pytest.mark.gpu
+def test_library_and_torch_share_one_hip_runtime_in_either_import_order():
+    """torch ships its own HIP runtime; a second copy in the process finds no device.  The
+    binding loads the library after torch whatever the caller's import order."""
+    import subprocess
+    import sys
+    code = ("import dsp_amd\nL = dsp_amd.lib()\nn = L.dspmi_device_count()\nimport torch\n"
+            "assert torch.cuda.is_available() and n >= 1 and L.dspmi_device_count() == n\n"
+            "x = torch.ones(1, 64, device='cuda')\n"
+            "y = dsp_amd.FirPlan([1.0, 1.0]).exec(x)\nassert float(y.sum()) == 127.0\nprint('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-800:]
