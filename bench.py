@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# RCCL between processes needs dmabuf IPC on these hosts (legacy IPC fails with
+# hipIpcGetMemHandle: invalid argument); keep the setting if the launcher did not export it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
