@@ -894,7 +894,7 @@ const OlsEntry kOls[] = {
     OLS(16, 1, 16, 1, 1, 1, 0),        OLS(32, 2, 4, 2, 4, 1, 2),          OLS(64, 4, 4, 4, 4, 1, 2),
     OLS(128, 8, 4, 8, 4, 1, 2),        OLS(256, 16, 16, 16, 1, 1, 2),      OLS(512, 32, 16, 2, 16, 1, 2),
     OLS(1024, 64, 16, 4, 16, 1, 2),    OLS(2048, 128, 16, 8, 16, 1, 2),    OLS(4096, 256, 16, 16, 16, 1, 3),
-    OLS(8192, 512, 16, 16, 2, 16, 3),  OLS(16384, 512, 16, 16, 4, 16, 3),
+    OLS(8192, 512, 16, 16, 2, 16, 3),  OLS(16384, 1024, 16, 16, 4, 16, 3),
 };
 
 // ---------------------------------------------------------------------------
