@@ -66,27 +66,39 @@ __device__ __forceinline__ void nt_store(C<T> q, C<T> *p)
     __builtin_nontemporal_store(v, reinterpret_cast<V2 *>(p));
 }
 
-// cos/sin of 2*pi*k/16, k = 0..15
-__device__ constexpr double kCos16[16] = {1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
-                                          0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
-                                          -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173,
-                                          0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613};
-__device__ constexpr double kSin16[16] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128675613,
-                                          1.0, 0.92387953251128675613, 0.70710678118654752440, 0.38268343236508977173,
-                                          0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128675613,
-                                          -1.0, -0.92387953251128675613, -0.70710678118654752440, -0.38268343236508977173};
+// cos/sin of 2*pi*k/32, k = 0..31
+__device__ constexpr double kCos32[32] = {
+    1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567,
+    0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135,
+    0.00000000000000006123, -0.19509032201612819257, -0.38268343236508972627, -0.55557023301960195560,
+    -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058,
+    -1.00000000000000000000, -0.98078528040323043058, -0.92387953251128684951, -0.83146961230254545772,
+    -0.70710678118654768376, -0.55557023301960217765, -0.38268343236509033689, -0.19509032201612866442,
+    -0.00000000000000018370, 0.19509032201612830359, 0.38268343236509000382, 0.55557023301960184458,
+    0.70710678118654735069, 0.83146961230254523567, 0.92387953251128651644, 0.98078528040323031956,
+};
+__device__ constexpr double kSin32[32] = {
+    0.00000000000000000000, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765,
+    0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058,
+    1.00000000000000000000, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772,
+    0.70710678118654757274, 0.55557023301960217765, 0.38268343236508989280, 0.19509032201612860891,
+    0.00000000000000012246, -0.19509032201612835911, -0.38268343236508967076, -0.55557023301960195560,
+    -0.70710678118654746172, -0.83146961230254523567, -0.92387953251128651644, -0.98078528040323031956,
+    -1.00000000000000000000, -0.98078528040323043058, -0.92387953251128662746, -0.83146961230254545772,
+    -0.70710678118654768376, -0.55557023301960217765, -0.38268343236509039240, -0.19509032201612871993,
+};
 
-// a * exp(-2*pi*i*K/16), K a compile-time constant; trivial factors cost no multiply
+// a * exp(-2*pi*i*K/32), K a compile-time constant; trivial factors cost no multiply
 template <int K, typename T>
-__device__ __forceinline__ C<T> mul_w16(C<T> a)
+__device__ __forceinline__ C<T> mul_w32(C<T> a)
 {
-    constexpr int k = K & 15;
+    constexpr int k = K & 31;
     if constexpr (k == 0) return a;
-    else if constexpr (k == 4) return mul_mi(a);
-    else if constexpr (k == 8) return {-a.re, -a.im};
-    else if constexpr (k == 12) return {-a.im, a.re};
+    else if constexpr (k == 8) return mul_mi(a);
+    else if constexpr (k == 16) return {-a.re, -a.im};
+    else if constexpr (k == 24) return {-a.im, a.re};
     else {
-        constexpr T c = (T)kCos16[k], s = (T)(-kSin16[k]);
+        constexpr T c = (T)kCos32[k], s = (T)(-kSin32[k]);
         return {a.re * c - a.im * s, a.re * s + a.im * c};
     }
 }
@@ -95,7 +107,7 @@ __device__ __forceinline__ C<T> mul_w16(C<T> a)
 template <int R, int RB, typename T, int... I>
 __device__ __forceinline__ void inner_twiddle(C<T> *t, std::integer_sequence<int, I...>)
 {
-    ((t[I] = mul_w16<(I / RB) * (I % RB) * (16 / R)>(t[I])), ...);
+    ((t[I] = mul_w32<(I / RB) * (I % RB) * (32 / R)>(t[I])), ...);
 }
 
 // Forward DFT of R points held in v[0], v[S], v[2S], ... (natural order in and out).
