@@ -7,9 +7,10 @@ CPU implementation of any routine here: if the library is missing or fails to
 load, importing the bindings raises.
 """
 from .lib import (  # noqa: F401
-    DspmiError, FirPlan, FftPlan, OlsPlan, ToneGen, power_spectrum, lib, lib_path,
-    PS_NORM_GUARDED, PS_NORM, PS_ABS,
+    DspmiError, FirPlan, FftPlan, OlsPlan, ToneGen, power_spectrum, phase, lib, lib_path,
+    PS_NORM_GUARDED, PS_NORM, PS_ABS, PS_PERCENT,
     conv0, conv1, convolve, convolve_alloc, fir, fir_set_taps,
     dft, idft, fft_r2c, fft_mag, filter, make_blackman_window, make_filter_kernel,
+    ps_percent, ps_abs, compute_phi,
     FORWARD, BACKWARD, F32, F64, FIR_DROP_FIRST,
 )

@@ -73,6 +73,29 @@ __device__ __forceinline__ double tone_cos(double w) { return tone_trig<true>(w)
 // mode 0: ps = |X| / sum if sum > 1e-5 else |X|      (fft/src/main.c:120-141)
 // mode 1: ps = |X| / sum                             (alsa/main.c:473-487)
 // mode 2: ps = 2|X| / scale                          (fftc/main.c:80-105)
+// mode 3: ps = (re - im) / sum if sum >= 1e-4        (ps_percent, fftc/main.c:46-77)
+template <typename T>
+__device__ __forceinline__ T bin_value(T re, T im, int mode)
+{
+    return mode == 3 ? re - im : sqrt(re * re + im * im);
+}
+
+// The divisor and factor a frame's values are scaled by, from the frame's sum.
+template <typename T>
+__device__ __forceinline__ void frame_scale(int mode, T sum, T scale, T &mul, T &div)
+{
+    mul = T(1);
+    div = T(1);
+    if (mode == 2) {
+        mul = T(2);
+        div = scale;
+    } else if (mode == 3) {
+        if (sum >= T(0.0001)) div = sum;
+    } else if (mode == 1 || sum > T(0.00001)) {
+        div = sum;
+    }
+}
+
 template <int PER_LANE>
 __global__ __launch_bounds__(256) void power_spectrum_kernel(float *__restrict__ ps, const C32 *__restrict__ bins,
                                                              unsigned nbin, unsigned in_stride, size_t batch, int mode,
@@ -91,19 +114,13 @@ __global__ __launch_bounds__(256) void power_spectrum_kernel(float *__restrict__
             float m = 0.f;
             if (k < nbin) {
                 const C32 v = src[k];
-                m = sqrtf(v.re * v.re + v.im * v.im);
+                m = bin_value(v.re, v.im, mode);
             }
             mag[q] = m;
             part += m;
         }
-        float div = 1.f, mul = 1.f;
-        if (mode == 2) {
-            mul = 2.f;
-            div = scale;
-        } else {
-            const float sum = wave_sum(part);
-            if (mode == 1 || sum > 0.00001f) div = sum;
-        }
+        float div, mul;
+        frame_scale(mode, mode == 2 ? 0.f : wave_sum(part), scale, mul, div);
 #pragma unroll
         for (int q = 0; q < PER_LANE; q++) {
             const unsigned k = lane + 64 * q;
@@ -112,33 +129,44 @@ __global__ __launch_bounds__(256) void power_spectrum_kernel(float *__restrict__
     }
 }
 
-// Frames too long for the register path: two passes over the bins.
-__global__ __launch_bounds__(256) void power_spectrum_long_kernel(float *__restrict__ ps, const C32 *__restrict__ bins,
-                                                                  unsigned nbin, unsigned in_stride, size_t batch, int mode,
-                                                                  float scale)
+// Frames too long for the register path, and the double-precision form behind the host
+// wrappers: two passes over the bins.
+template <typename T>
+__device__ __forceinline__ T wave_sum_t(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void power_spectrum_long_kernel(T *__restrict__ ps, const T *__restrict__ bins, unsigned nbin,
+                                                                  unsigned in_stride, size_t batch, int mode, T scale)
 {
     const unsigned lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t f = wave; f < batch; f += nwaves) {
-        const C32 *src = bins + f * in_stride;
-        float part = 0.f;
-        for (unsigned k = lane; k < nbin; k += 64) {
-            const C32 v = src[k];
-            part += sqrtf(v.re * v.re + v.im * v.im);
-        }
-        float div = 1.f, mul = 1.f;
-        if (mode == 2) {
-            mul = 2.f;
-            div = scale;
-        } else {
-            const float sum = wave_sum(part);
-            if (mode == 1 || sum > 0.00001f) div = sum;
-        }
-        for (unsigned k = lane; k < nbin; k += 64) {
-            const C32 v = src[k];
-            ps[f * nbin + k] = (mul * sqrtf(v.re * v.re + v.im * v.im)) / div;
-        }
+        const T *src = bins + 2 * f * in_stride;  // interleaved re, im
+        T part = T(0);
+        for (unsigned k = lane; k < nbin; k += 64) part += bin_value(src[2 * k], src[2 * k + 1], mode);
+        T div, mul;
+        frame_scale(mode, mode == 2 ? T(0) : wave_sum_t(part), scale, mul, div);
+        for (unsigned k = lane; k < nbin; k += 64) ps[f * nbin + k] = (mul * bin_value(src[2 * k], src[2 * k + 1], mode)) / div;
+    }
+}
+
+// phi = atan(im / re) where |re| >= 1e-5, else 0 (compute_phi, fftc/main.c:108-123)
+template <typename T>
+__global__ __launch_bounds__(256) void phase_kernel(T *__restrict__ phi, const T *__restrict__ bins, unsigned nbin,
+                                                    unsigned in_stride, size_t batch)
+{
+    const size_t total = batch * (size_t)nbin;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t f = i / nbin;
+        const size_t k = i - f * nbin;
+        const T re = bins[2 * (f * in_stride + k)], im = bins[2 * (f * in_stride + k) + 1];
+        phi[i] = fabs(re) >= T(0.00001) ? atan(im / re) : T(0);
     }
 }
 
@@ -395,7 +423,7 @@ int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigne
 {
     if (batch == 0 || nbin == 0) return DSPMI_OK;
     if (!ps || !bins) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: null buffer");
-    if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: mode must be 0, 1 or 2");
+    if (mode < 0 || mode > 3) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: mode must be 0..3");
     if (in_stride < nbin) return dspmi::fail(DSPMI_EINVAL, "power_spectrum: in_stride < nbin");
     hipStream_t s = static_cast<hipStream_t>(stream);
     size_t blocks = (batch + 3) / 4;
@@ -406,7 +434,21 @@ int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigne
     else if (nbin <= 64 * 33)
         hipLaunchKernelGGL(power_spectrum_kernel<33>, dim3((unsigned)blocks), dim3(256), 0, s, ps, b, nbin, in_stride, batch, mode, scale);
     else
-        hipLaunchKernelGGL(power_spectrum_long_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ps, b, nbin, in_stride, batch, mode, scale);
+        hipLaunchKernelGGL(power_spectrum_long_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, ps,
+                           static_cast<const float *>(bins), nbin, in_stride, batch, mode, scale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int dspmi_phase_f32(float *phi, const void *bins, unsigned nbin, unsigned in_stride, size_t batch, void *stream)
+{
+    if (batch == 0 || nbin == 0) return DSPMI_OK;
+    if (!phi || !bins) return dspmi::fail(DSPMI_EINVAL, "phase: null buffer");
+    if (in_stride < nbin) return dspmi::fail(DSPMI_EINVAL, "phase: in_stride < nbin");
+    size_t blocks = (batch * (size_t)nbin + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(phase_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), phi,
+                       static_cast<const float *>(bins), nbin, in_stride, batch);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
@@ -460,3 +502,28 @@ int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan,
 }
 
 }  // extern "C"
+
+// Double-precision forms used by the host wrappers (one frame per call there).
+namespace dspmi {
+
+int power_spectrum_f64(double *ps, const double *bins, unsigned nbin, unsigned in_stride, size_t batch, int mode, double scale,
+                       hipStream_t s)
+{
+    size_t blocks = (batch + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(power_spectrum_long_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, ps, bins, nbin, in_stride,
+                       batch, mode, scale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int phase_f64(double *phi, const double *bins, unsigned nbin, unsigned in_stride, size_t batch, hipStream_t s)
+{
+    size_t blocks = (batch * (size_t)nbin + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(phase_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, s, phi, bins, nbin, in_stride, batch);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+}  // namespace dspmi

@@ -18,6 +18,9 @@ int dspmi_fir_exec_f64_desc(dspmi_fir_t plan, double *y, size_t y_stride, unsign
 namespace dspmi {
 int ps_abs_f64(const void *bins, double *out, unsigned nout, double scale, size_t batch, unsigned in_stride,
                hipStream_t s);
+int power_spectrum_f64(double *ps, const double *bins, unsigned nbin, unsigned in_stride, size_t batch, int mode, double scale,
+                       hipStream_t s);
+int phase_f64(double *phi, const double *bins, unsigned nbin, unsigned in_stride, size_t batch, hipStream_t s);
 }  // namespace dspmi
 
 namespace {
@@ -154,6 +157,24 @@ void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx)
     DSPMI_HIP_OR_DIE(hipMemcpy(xx, dmag.p, (size_t)(nx / 2) * sizeof(double), hipMemcpyDeviceToHost));
     DSPMI_OR_DIE(dspmi_fft_destroy(plan));
 }
+
+// nx/2 values read out of a transform of nx points: `mode` of the spectrum kernel, or the phase
+static void run_readout(double (*x)[2], unsigned nx, double *out, int mode)
+{
+    const unsigned nbin = nx / 2;
+    if (nbin == 0) return;
+    DevBuf din((size_t)nbin * 2 * sizeof(double)), dout((size_t)nbin * sizeof(double));
+    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, x, (size_t)nbin * 2 * sizeof(double), hipMemcpyHostToDevice));
+    if (mode < 0) DSPMI_OR_DIE(dspmi::phase_f64(dout.as<double>(), din.as<double>(), nbin, nbin, 1, nullptr));
+    else DSPMI_OR_DIE(dspmi::power_spectrum_f64(dout.as<double>(), din.as<double>(), nbin, nbin, 1, mode, (double)nx, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(out, dout.p, (size_t)nbin * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+void dsp_ps_percent(double (*x)[2], unsigned int nx, double *xx) { run_readout(x, nx, xx, DSPMI_PS_PERCENT); }
+
+void dsp_ps_abs(double (*x)[2], unsigned int nx, double *xx) { run_readout(x, nx, xx, DSPMI_PS_ABS); }
+
+void dsp_compute_phi(double (*x)[2], unsigned int nx, double *phi) { run_readout(x, nx, phi, -1); }
 
 void dsp_make_blackman_window(double *x, unsigned int nx)
 {

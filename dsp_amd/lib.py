@@ -74,6 +74,10 @@ _SIGS = {
     "dsp_fft_r2c": (None, [_dp, _dp, _u]),
     "dsp_fft_mag": (None, [_dp, _u, _dp]),
     "dsp_filter": (None, [_dp, _dp, _u, _dp]),
+    "dsp_ps_percent": (None, [_dp, _u, _dp]),
+    "dsp_ps_abs": (None, [_dp, _u, _dp]),
+    "dsp_compute_phi": (None, [_dp, _u, _dp]),
+    "dspmi_phase_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, _vp]),
     "dsp_make_blackman_window": (None, [_dp, _u]),
     "dsp_make_filter_kernel": (None, [_dp, _u, _dp]),
 }
@@ -291,7 +295,7 @@ class FftPlan:
             pass
 
 
-PS_NORM_GUARDED, PS_NORM, PS_ABS = 0, 1, 2
+PS_NORM_GUARDED, PS_NORM, PS_ABS, PS_PERCENT = 0, 1, 2, 3
 
 
 def power_spectrum(bins, nbin=None, mode=PS_NORM_GUARDED, scale=1.0, out=None):
@@ -305,6 +309,19 @@ def power_spectrum(bins, nbin=None, mode=PS_NORM_GUARDED, scale=1.0, out=None):
         out = torch.empty((batch, nbin), dtype=torch.float32, device=bins.device)
     _check(lib().dspmi_power_spectrum_f32(out.data_ptr(), bins.data_ptr(), nbin, nspec, batch, mode, scale, _stream()),
            "power_spectrum")
+    return out
+
+
+def phase(bins, nbin=None, out=None):
+    """compute_phi (fftc/main.c:108-123) over the first nbin bins of each frame."""
+    import torch
+    assert bins.is_cuda and bins.dtype == torch.complex64 and bins.dim() == 2 and bins.is_contiguous()
+    batch, nspec = bins.shape
+    if nbin is None:
+        nbin = nspec
+    if out is None:
+        out = torch.empty((batch, nbin), dtype=torch.float32, device=bins.device)
+    _check(lib().dspmi_phase_f32(out.data_ptr(), bins.data_ptr(), nbin, nspec, batch, _stream()), "phase")
     return out
 
 
@@ -486,6 +503,28 @@ def fft_mag(z):
     out = np.empty(len(z) // 2)
     lib().dsp_fft_mag(zp, len(z), out.ctypes.data_as(_dp))
     return out
+
+
+def _readout(fn, z):
+    z, zp = _c(z)
+    out = np.empty(len(z) // 2)
+    fn(zp, len(z), out.ctypes.data_as(_dp))
+    return out
+
+
+def ps_percent(z):
+    """fftc/main.c:46-77 -- (re - im) over nx/2 bins, divided by their sum when it reaches 1e-4."""
+    return _readout(lib().dsp_ps_percent, z)
+
+
+def ps_abs(z):
+    """fftc/main.c:80-105 -- 2|X|/nx over nx/2 bins of a transform."""
+    return _readout(lib().dsp_ps_abs, z)
+
+
+def compute_phi(z):
+    """fftc/main.c:108-123 -- atan(im/re) where |re| >= 1e-5, else 0."""
+    return _readout(lib().dsp_compute_phi, z)
 
 
 def filter(x, coeffs):  # noqa: A001 - the reference's name

@@ -54,6 +54,11 @@ static inline void convolve(double *xx, unsigned int nxx, const double *x, unsig
 static inline void dft(fftw_complex *in, unsigned int nx, fftw_complex *out) { dsp_dft(in, nx, out); }
 static inline void idft(fftw_complex *in, unsigned int nx, fftw_complex *out) { dsp_idft(in, nx, out); }
 
+/* fftc/main.c:46-123: read-outs of a transform (nx/2 values each) */
+static inline void ps_percent(fftw_complex *x, unsigned int nx, double *xx) { dsp_ps_percent(x, nx, xx); }
+static inline void ps_abs(fftw_complex *x, unsigned int nx, double *xx) { dsp_ps_abs(x, nx, xx); }
+static inline void compute_phi(fftw_complex *x, unsigned int nx, double *phi) { dsp_compute_phi(x, nx, phi); }
+
 #ifdef DSP_DROPIN_MAGNITUDE_FFT
 /* fir/src/main.c:229-255 */
 static inline void fft(fftw_complex *x, unsigned int nx, double *xx) { dsp_fft_mag(x, nx, xx); }

@@ -208,11 +208,17 @@ int dspmi_ols_exec_f32(dspmi_ols_t plan, float *y, size_t y_stride, const float 
 #define DSPMI_PS_NORM_GUARDED 0 /* |X|/sum if sum > 1e-5 else |X|: fft/src/main.c:120-141, util/fft/fft.c:73-94 */
 #define DSPMI_PS_NORM         1 /* |X|/sum, no guard: alsa/main.c:473-487 */
 #define DSPMI_PS_ABS          2 /* 2|X|/scale: fftc/main.c:80-105, fir/src/main.c:246-251 */
+#define DSPMI_PS_PERCENT      3 /* (re - im)/sum if sum >= 1e-4 else re - im: ps_percent, fftc/main.c:46-77 */
 
 /* ps[f][k] for k < nbin from bins[f][k] (dspmi_c32, in_stride complex elements between
  * frames, so the first nbin bins of a longer spectrum can be used in place). */
 int dspmi_power_spectrum_f32(float *ps, const void *bins, unsigned nbin, unsigned in_stride,
                              size_t batch, int mode, float scale, void *stream);
+
+/* phi[f][k] = atan(im/re) of bins[f][k] where |re| >= 1e-5, else 0: compute_phi of
+ * fftc/main.c:108-123, same layout as dspmi_power_spectrum_f32. */
+int dspmi_phase_f32(float *phi, const void *bins, unsigned nbin, unsigned in_stride, size_t batch,
+                    void *stream);
 
 /* Real frames straight to their magnitude spectrum (r2c + dspmi_power_spectrum_f32 in one
  * pass over memory): in [batch][n] reals, ps [batch][nbin] with nbin = n/2+1 (fft/src) or n/2
@@ -278,6 +284,13 @@ void dsp_idft(double (*in)[2], unsigned int nx, double (*out)[2]);
 void dsp_fft_r2c(double *xx, const double *x, unsigned int n);
 /* fir/src/main.c:229-255: xx[i] = 2|X[i]|/nx for i < nx/2 */
 void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx);
+
+/* The spectrum read-outs of fftc/main.c over a transform x of nx points, nx/2 values each:
+ * ps_percent (:46-77), ps_abs (:80-105), compute_phi (:108-123).  ps_percent's sum runs in
+ * another order than the reference's loop: results agree to a few ulp, not bit for bit. */
+void dsp_ps_percent(double (*x)[2], unsigned int nx, double *xx);
+void dsp_ps_abs(double (*x)[2], unsigned int nx, double *xx);
+void dsp_compute_phi(double (*x)[2], unsigned int nx, double *phi);
 /* make_blackman_window (fir/src/main.c:138-146): 0.42 - 0.5 cos(2 pi i/nx) + 0.08 cos(4 pi i/nx). */
 void dsp_make_blackman_window(double *x, unsigned int nx);
 

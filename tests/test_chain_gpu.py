@@ -163,3 +163,30 @@ def test_fused_r2c_spectrum(n):
         mag = np.abs(want_bins[:n // 2])
         assert rel_l2(ps1[f], mag / mag.sum()) <= 1e-5
         assert rel_l2(ps2[f], 2 * mag / n) <= 1e-5
+
+
+@pytest.mark.parametrize("nx", [2, 480, 1024, 5000])
+def test_transform_readouts_of_the_fftc_demo(nx):
+    """ps_percent, ps_abs, compute_phi (fftc/main.c:46-123): host routines in double, and the batched
+    f32 device forms; a frame whose sum stays under ps_percent's 1e-4 guard is left unscaled and real
+    parts under 1e-5 give a zero phase."""
+    rng = np.random.default_rng(nx)
+    z = rng.uniform(-1, 1, nx) + 1j * rng.uniform(-1, 1, nx)
+    z[: nx // 2].real += 0.7                       # a sum clearly above the guard
+    z[0] = 3e-6 + 0.5j                             # |re| below 1e-5: phase 0
+    np.testing.assert_allclose(dsp_amd.ps_percent(z), oracle.ps_percent(z), rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(dsp_amd.ps_abs(z), oracle.ps_abs(z), rtol=1e-15, atol=0)   # the device may fuse re*re + im*im
+    np.testing.assert_allclose(dsp_amd.compute_phi(z), oracle.compute_phi(z), rtol=1e-14, atol=1e-16)
+    assert dsp_amd.compute_phi(z)[0] == 0.0
+    tiny = z * 1e-7
+    np.testing.assert_allclose(dsp_amd.ps_percent(tiny), oracle.ps_percent(tiny), rtol=1e-12, atol=1e-20)
+    # device forms, three frames: the one above, its negative (sum < 0: unscaled), a tiny one
+    frames = np.stack([z, -z, tiny]).astype(np.complex64)
+    zd = torch.from_numpy(frames).cuda()
+    nb = nx // 2
+    got = dsp_amd.power_spectrum(zd, nb, dsp_amd.PS_PERCENT).cpu().numpy()
+    phi = dsp_amd.phase(zd, nb).cpu().numpy()
+    for f in range(3):
+        zz = frames[f].astype(np.complex128)
+        np.testing.assert_allclose(got[f], oracle.ps_percent(zz), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(phi[f], oracle.compute_phi(zz), rtol=2e-6, atol=1e-6)
