@@ -174,12 +174,15 @@ __global__ __launch_bounds__(256) void phase_kernel(T *__restrict__ phi, const T
 // 64 channels per workgroup of 64 lanes; each lane advances its channel 64 samples, the
 // tile is transposed through LDS and written as 64 rows of 256 contiguous bytes.
 // O = float: samples as floats; O = int: one interleaved 16-bit stereo frame per sample, both
-// channels (int16_t)value (tonegen/main.c:14-24).
+// channels (int16_t)value (tonegen/main.c:14-24); O = C32: complex samples with zero imaginary
+// part (tonegen_read_complex, tonegen/tonegen.c:42-59).
 template <typename O>
 __device__ __forceinline__ O tone_out(double v)
 {
     if constexpr (std::is_floating_point<O>::value) {
         return (O)v;
+    } else if constexpr (std::is_same<O, C32>::value) {
+        return C32{(float)v, 0.f};  // tonegen_read_complex: the imaginary part is always 0
     } else {
         // the cast as an x86 build performs it: truncate to 32 bits (out of range -> 0x80000000), low half
         const unsigned h = (v > -2147483649.0 && v < 2147483648.0) ? ((unsigned)(int)v & 0xffffu) : 0u;
@@ -492,6 +495,13 @@ int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, uns
                       const double *amp, const double *phi, int use_sin, unsigned flags, void *stream)
 {
     return tonegen_run<float>(x, x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, flags, stream);
+}
+
+int dspmi_tonegen_c32(void *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,
+                      const double *amp, const double *phi, int use_sin, unsigned flags, void *stream)
+{
+    if (reinterpret_cast<uintptr_t>(x) & 7) return dspmi::fail(DSPMI_EINVAL, "tonegen: output must be 8-byte aligned");
+    return tonegen_run<C32>(static_cast<C32 *>(x), x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin, flags, stream);
 }
 
 int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone, double *w, const double *dw,

@@ -62,6 +62,7 @@ _SIGS = {
     "dspmi_fft_exec_r2c_spectrum_s16x2": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
     "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
+    "dspmi_tonegen_c32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
     "dspmi_tonegen_s16x2": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
@@ -352,6 +353,15 @@ class ToneGen:
         _check(lib().dspmi_tonegen_f32(out.data_ptr(), out.stride(0) if self.nchan > 1 else n, n, self.nchan, self.ntone,
                                        self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
                                        int(self.use_sin), 1 if sequential else 0, _stream()), "tonegen")
+        return out
+
+    def read_complex(self, n, sequential=False):
+        """Next n samples of every channel as complex64 with zero imaginary part (tonegen_read_complex)."""
+        import torch
+        out = torch.empty((self.nchan, n), dtype=torch.complex64, device=self.w.device)
+        _check(lib().dspmi_tonegen_c32(out.data_ptr(), n, n, self.nchan, self.ntone,
+                                       self.w.data_ptr(), self.dw.data_ptr(), self.amp.data_ptr(), self.phi.data_ptr(),
+                                       int(self.use_sin), 1 if sequential else 0, _stream()), "tonegen_c32")
         return out
 
     def read_s16x2(self, n, sequential=False):

@@ -248,6 +248,12 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
 int dspmi_tonegen_f32(float *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
                       double *w, const double *dw, const double *amp, const double *phi,
                       int use_sin, unsigned flags, void *stream);
+/* Same generator, samples stored as complex points with a zero imaginary part -- the input
+ * tonegen_read_complex (tonegen/tonegen.c:42-59) hands the c2c transform in fftc/main.c:146-158.
+ * x: dspmi_c32 elements, x_stride in complex elements, 8-byte aligned. */
+int dspmi_tonegen_c32(void *x, size_t x_stride, unsigned n, unsigned nchan, unsigned ntone,
+                      double *w, const double *dw, const double *amp, const double *phi,
+                      int use_sin, unsigned flags, void *stream);
 /* Same generator, samples stored as interleaved 16-bit stereo frames: (int16_t)value in both
  * channels (convert_double_to_s16x2, tonegen/main.c:14-24).  x_stride in frames.  The sum is
  * formed in double as above; its cosines may differ from the host libm's in the last bit, so a

@@ -190,3 +190,27 @@ def test_transform_readouts_of_the_fftc_demo(nx):
         zz = frames[f].astype(np.complex128)
         np.testing.assert_allclose(got[f], oracle.ps_percent(zz), rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(phi[f], oracle.compute_phi(zz), rtol=2e-6, atol=1e-6)
+
+
+def test_tonegen_complex_output_feeds_the_c2c_transform():
+    """tonegen_read_complex (tonegen/tonegen.c:42-59) on the device, then the fftc demo's transform
+    of it (fftc/main.c:146-158: tones of amplitude 100 at 2, 4 and 6 kHz, 480 points at 48 kHz)."""
+    fs, n = 48000.0, 480
+    freqs = [[2000.0, 4000.0, 6000.0]] * 3
+    amps = [[100.0, 100.0, 100.0]] * 3
+    phis = [[0.0, 0.666, 0.0]] * 3
+    gen = dsp_amd.ToneGen(fs, freqs, amps, phis)
+    ref = dsp_amd.ToneGen(fs, freqs, amps, phis)
+    z = gen.read_complex(n)
+    x = ref.read(n)
+    assert torch.equal(z.real, x) and int(z.imag.abs().max()) == 0
+    z2 = gen.read_complex(100, sequential=True)           # the stream continues where it stopped
+    assert torch.equal(z2.real, ref.read(100, sequential=True))
+    t = oracle.Tonegen()
+    for j in range(3):
+        t.add(fs, freqs[0][j], amps[0][j], phis[0][j])
+    want = t.read_complex(n)
+    np.testing.assert_allclose(z[0].cpu().numpy(), want, rtol=0, atol=2e-5)
+    spec = dsp_amd.FftPlan(n, "f32").c2c(z).cpu().numpy()
+    peaks = np.argsort(-np.abs(spec[0][: n // 2]))[:3]
+    assert sorted(peaks) == [20, 40, 60]                  # 2, 4, 6 kHz at 100 Hz per bin
