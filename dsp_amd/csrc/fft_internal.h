@@ -51,4 +51,11 @@ struct OlsLaunch {
 typedef int (*ols_launch_fn)(const OlsLaunch &o, const void *tw, int num_cu, hipStream_t s);
 ols_launch_fn ols_find(unsigned n);
 
+// Any-length transform in one kernel (Bluestein over an M-point convolution, f32): in/out =
+// batch frames of n complex points, chirp[m] = exp(-i pi m^2 / n) (n entries), filt =
+// FFT_M(conj(chirp) laid out circularly) / M, tw = exp(-2 pi i k / M).  in == out is allowed.
+typedef int (*bluestein_launch_fn)(const void *in, void *out, const void *chirp, const void *filt, const void *tw, unsigned n,
+                                   size_t batch, int backward, int num_cu, hipStream_t s);
+bluestein_launch_fn bluestein_find(unsigned m, int precision);
+
 }  // namespace dspmi

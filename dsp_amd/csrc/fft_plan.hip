@@ -5,7 +5,8 @@
 //  * power-of-two lengths run the Stockham kernels directly;
 //  * any other length (the demos use 480 and 482: fftc/main.c:137, fir/src/main.c:154)
 //    runs Bluestein's chirp-z: x[n]*c[n] convolved with conj(c) through two
-//    power-of-two transforms of length M >= 2n-1, c[n] = exp(-i*pi*n^2/N);
+//    power-of-two transforms of length M >= 2n-1, c[n] = exp(-i*pi*n^2/N) -- in one fused
+//    kernel for f32 (fft_stockham.hip), as five kernels for f64;
 //  * real transforms of even length n use one complex transform of n/2 points plus an
 //    O(n) split / merge kernel; other real lengths go through the complex transform.
 //
@@ -282,6 +283,7 @@ struct dspmi_fft_plan {
     unsigned M = 0;
     const dspmi::FftKernel *kern_M = nullptr;
     void *tw_M = nullptr, *chirp = nullptr, *filt = nullptr;
+    dspmi::bluestein_launch_fn blu = nullptr;  // fused form, or nullptr
     // scratch, grown on demand (allocation happens in exec only when a batch outgrows it)
     void *work[4] = {nullptr, nullptr, nullptr, nullptr};  // 0: Bluestein, 1: real transforms, 2: spectrum bins, 3: converted input
     size_t work_bytes[4] = {0, 0, 0, 0};
@@ -314,7 +316,9 @@ template <typename T>
 int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int backward, hipStream_t s)
 {
     if (pl->kern) return run_pow2(pl->kern, in, out, pl->tw_n, batch, backward, pl->esz, pl->num_cu, s);
-    // Bluestein
+    // Bluestein: one kernel where it exists (DSPMI_BLUESTEIN_COMPOSED=1: the five separate ones)
+    if (pl->blu && !getenv("DSPMI_BLUESTEIN_COMPOSED"))
+        return pl->blu(in, out, pl->chirp, pl->filt, pl->tw_M, pl->n, batch, backward, pl->num_cu, s);
     const unsigned n = pl->n, M = pl->M;
     int rc = ensure_work(pl, 0, batch * (size_t)M * sizeof(C<T>));
     if (rc != DSPMI_OK) return rc;
@@ -568,8 +572,10 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     pl->kern = k;
     pl->kern_half = kh;
     pl->kern_M = kM;
+    if (kM) pl->blu = dspmi::bluestein_find(M, precision);
     pl->M = M;
     if (k) snprintf(pl->name, sizeof pl->name, "%s", k->name);
+    else if (kM && pl->blu) snprintf(pl->name, sizeof pl->name, "bluestein_n%u_m%u_one_kernel", n, M);
     else if (kM) snprintf(pl->name, sizeof pl->name, "bluestein_n%u_via_%s", n, kM->name);
     else snprintf(pl->name, sizeof pl->name, "fft_n1");
     hipDeviceProp_t prop;

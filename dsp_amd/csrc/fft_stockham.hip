@@ -910,6 +910,130 @@ const OlsEntry kOls[] = {
 };
 
 // ---------------------------------------------------------------------------
+// any length n through a power-of-two convolution (Bluestein), one kernel
+// ---------------------------------------------------------------------------
+
+// X[k] = c[k] * sum_m (x[m] c[m]) conj(c)[k-m],  c[m] = exp(-i pi m^2 / n): the frame times the
+// chirp, zero-extended to M >= 2n-1 points, is convolved with conj(c) through two M-point
+// transforms (filt = FFT_M(conj c laid out circularly) / M) and multiplied by the chirp again.
+// Same shape as the overlap-save kernel: with a symmetric radix list the spectrum is multiplied
+// in registers and goes straight back, so a frame costs one read and one write of n points
+// instead of the five passes over M points of the separate kernels.
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW>
+__global__ __launch_bounds__(block_threads<NT>()) void bluestein_fused_kernel(const C<T> *in, C<T> *out,
+                                                                              const C<T> *__restrict__ chirp,
+                                                                              const C<T> *__restrict__ filt,
+                                                                              const C<T> *__restrict__ tw, unsigned n,
+                                                                              size_t batch, int backward)
+{
+    static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
+    constexpr int P = N / NT;
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
+    static_assert(RLAST == R0, "first and last radix must match");
+    constexpr int STEP = N / R0;
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned slot = threadIdx.x / NT;
+    const unsigned tl = threadIdx.x % NT;
+    C<T> *lds = reinterpret_cast<C<T> *>(smem_raw) + (size_t)slot * padded_len(N);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    if constexpr (TW == 2) setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    if constexpr (TW == 3) setup_lds_twiddles_split<T, N, BT, FPB, R0, R1>(smem_raw, tw, tw1, tw2, tw3);
+    const T sgn = backward ? T(-1) : T(1);  // backward = conj . forward . conj
+
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    for (size_t fb = blockIdx.x; fb < nfb; fb += gridDim.x) {
+        const size_t frame = fb * FPB + slot;
+        const bool active = frame < batch;
+        const C<T> *src = in + frame * n;
+        // laundered lane index: the chirp and filter addresses are the same for every frame, and
+        // hoisting those loads out of the frame loop would cost their registers through both transforms
+        unsigned te = tl;
+        asm volatile("" : "+v"(te));
+        C<T> v[P];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const unsigned m = te + NT * (i / R0) + (i % R0) * STEP;
+            C<T> q = {T(0), T(0)};
+            if (active && m < n) {
+                q = src[m];
+                q.im *= sgn;
+                q = cmul(q, chirp[m]);
+            }
+            v[i] = q;
+        }
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
+        {
+            unsigned th = tl;
+            asm volatile("" : "+v"(th));
+            const C<T> *fp = filt + th;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const C<T> m = cmul(v[i], fp[NT * (i / R0) + (i % R0) * STEP]);
+                v[i] = {m.re, -m.im};
+            }
+        }
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
+        if (active) {
+            C<T> *dst = out + frame * n;
+            unsigned to = tl;
+            asm volatile("" : "+v"(to));
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const unsigned k = to + NT * (i / R0) + (i % R0) * STEP;
+                if (k < n) {
+                    C<T> q = cmul(C<T>{v[i].re, -v[i].im}, chirp[k]);
+                    q.im *= sgn;
+                    dst[k] = q;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW>
+int launch_bluestein(const void *in, void *out, const void *chirp, const void *filt, const void *tw, unsigned n, size_t batch,
+                     int backward, int num_cu, hipStream_t s)
+{
+    constexpr int BT = block_threads<NT>();
+    constexpr int FPB = BT / NT;
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(TW, R0, R1, R2, R3, N)) * sizeof(C<T>);
+    auto kern = bluestein_fused_kernel<T, N, NT, R0, R1, R2, R3, TW>;
+    static dspmi::PerDeviceOnce attr;
+    if (lds > 48 * 1024 && attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    if (batch == 0) return DSPMI_OK;
+    const size_t nfb = (batch + FPB - 1) / FPB;
+    size_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 2048 / BT) per_cu = 2048 / BT;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = (size_t)num_cu * per_cu;
+    if (grid > nfb) grid = nfb;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), static_cast<C<T> *>(out),
+                       static_cast<const C<T> *>(chirp), static_cast<const C<T> *>(filt), static_cast<const C<T> *>(tw), n, batch,
+                       backward);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+struct BluesteinEntry {
+    unsigned m;
+    dspmi::bluestein_launch_fn fn;
+};
+#define BLU(N, NT, A, B, C_, D, TW) {N, launch_bluestein<float, N, NT, A, B, C_, D, TW>}
+const BluesteinEntry kBluesteinF32[] = {
+    BLU(16, 1, 16, 1, 1, 1, 0),       BLU(32, 2, 4, 2, 4, 1, 2),         BLU(64, 4, 4, 4, 4, 1, 2),
+    BLU(128, 8, 4, 8, 4, 1, 2),       BLU(256, 16, 16, 16, 1, 1, 2),     BLU(512, 32, 16, 2, 16, 1, 2),
+    BLU(1024, 64, 16, 4, 16, 1, 2),   BLU(2048, 128, 16, 8, 16, 1, 2),   BLU(4096, 256, 16, 16, 16, 1, 3),
+    BLU(8192, 512, 16, 16, 2, 16, 3), BLU(16384, 1024, 16, 16, 4, 16, 3),
+};
+
+// ---------------------------------------------------------------------------
 // launchers and the kernel table
 // ---------------------------------------------------------------------------
 
@@ -1091,6 +1215,14 @@ const FftEntry *find_entry(unsigned n, int precision)
 namespace dspmi {
 
 const FftKernel *fft_find(unsigned n, int precision) { return find_entry(n, precision); }
+
+bluestein_launch_fn bluestein_find(unsigned m, int precision)
+{
+    if (precision != DSPMI_F32) return nullptr;
+    for (const BluesteinEntry &e : kBluesteinF32)
+        if (e.m == m) return e.fn;
+    return nullptr;
+}
 
 ols_launch_fn ols_find(unsigned n)
 {

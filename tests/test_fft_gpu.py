@@ -299,3 +299,28 @@ def test_lengths_no_kernel_covers_are_refused():
         got = plan.c2c(z).cpu().numpy()
         want = np.fft.fft(z.cpu().numpy().astype(np.complex128), axis=1)
         assert rel_l2(got, want) <= (TOL_FFT if dtype == "f32" else TOL_F64)
+
+
+@pytest.mark.parametrize("n,batch", [(5, 3), (9, 70), (100, 33), (480, 17), (482, 4), (1000, 9), (3000, 5), (8191, 2)])
+def test_any_length_one_kernel_form(n, batch, monkeypatch):
+    """Lengths that are not powers of two run Bluestein's convolution in one kernel (f32); the five
+    separate kernels are the same arithmetic.  Both directions, ragged batches, in place."""
+    rng = np.random.default_rng(n * 7 + batch)
+    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
+    plan = dsp_amd.FftPlan(n, "f32")
+    zd = torch.from_numpy(z).cuda()
+    fwd = plan.c2c(zd, dsp_amd.FORWARD)
+    bwd = plan.c2c(zd, dsp_amd.BACKWARD)
+    buf = zd.clone()
+    plan.c2c(buf, dsp_amd.FORWARD, out=buf)
+    assert torch.equal(buf, fwd)
+    monkeypatch.setenv("DSPMI_BLUESTEIN_COMPOSED", "1")
+    fwd_c = plan.c2c(zd, dsp_amd.FORWARD).cpu().numpy()
+    monkeypatch.delenv("DSPMI_BLUESTEIN_COMPOSED")
+    fwd, bwd = fwd.cpu().numpy(), bwd.cpu().numpy()
+    for f in sorted({0, batch // 2, batch - 1}):
+        zz = z[f].astype(np.complex128)
+        want = np.fft.fft(zz) if n > 2048 else oracle.dft(zz, -1, "direct")
+        assert rel_l2(fwd[f], want) <= TOL_FFT, (f, rel_l2(fwd[f], want))
+        assert rel_l2(fwd_c[f], want) <= TOL_FFT
+        assert rel_l2(bwd[f], np.conj(np.fft.fft(np.conj(zz)))) <= TOL_FFT
