@@ -7,8 +7,9 @@
 //    runs Bluestein's chirp-z: x[n]*c[n] convolved with conj(c) through two
 //    power-of-two transforms of length M >= 2n-1, c[n] = exp(-i*pi*n^2/N) -- in one fused
 //    kernel for f32 (fft_stockham.hip), as five kernels for f64;
-//  * real transforms of even length n use one complex transform of n/2 points plus an
-//    O(n) split / merge kernel; other real lengths go through the complex transform.
+//  * real transforms of even length n use one complex transform of n/2 points (a power-of-two
+//    kernel, or a Bluestein plan of its own) plus an O(n) split / merge step -- inside the
+//    transform kernel where that exists; odd lengths go through the full complex transform.
 //
 // All transforms are unnormalised in both directions (FFTW's convention).
 #include "common.h"
@@ -284,6 +285,9 @@ struct dspmi_fft_plan {
     const dspmi::FftKernel *kern_M = nullptr;
     void *tw_M = nullptr, *chirp = nullptr, *filt = nullptr;
     dspmi::bluestein_launch_fn blu = nullptr;  // fused form, or nullptr
+    // even n whose half is not a power of two: real transforms run the n/2-point complex plan
+    // (itself Bluestein) around the same split / merge kernels
+    dspmi_fft_plan *half_plan = nullptr;
     // scratch, grown on demand (allocation happens in exec only when a batch outgrows it)
     void *work[4] = {nullptr, nullptr, nullptr, nullptr};  // 0: Bluestein, 1: real transforms, 2: spectrum bins, 3: converted input
     size_t work_bytes[4] = {0, 0, 0, 0};
@@ -404,7 +408,18 @@ int r2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
-    // any other length: complexify, full transform, keep bins 0..n/2
+    if (pl->half_plan) {
+        int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
+        if (rc != DSPMI_OK) return rc;
+        rc = c2c_typed<T>(pl->half_plan, in, pl->work[1], batch, 0, s);
+        if (rc != DSPMI_OK) return rc;
+        hipLaunchKernelGGL(r2c_split_kernel<T>, dim3(ew_grid(batch * (n / 2 + 1), pl->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<T> *>(pl->work[1]), static_cast<C<T> *>(out),
+                           static_cast<const C<T> *>(pl->tw_n), n, batch);
+        DSPMI_HIP(hipGetLastError());
+        return DSPMI_OK;
+    }
+    // odd lengths: complexify, full transform, keep bins 0..n/2
     int rc = ensure_work(pl, 1, 2 * batch * (size_t)n * sizeof(C<T>));
     if (rc != DSPMI_OK) return rc;
     C<T> *za = static_cast<C<T> *>(pl->work[1]);
@@ -445,6 +460,15 @@ int c2r_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, hipSt
                            static_cast<const C<T> *>(pl->tw_n), n, batch);
         DSPMI_HIP(hipGetLastError());
         return run_pow2(pl->kern_half, pl->work[1], out, pl->tw_half, batch, 1, pl->esz, pl->num_cu, s);
+    }
+    if (pl->half_plan) {
+        int rc = ensure_work(pl, 1, batch * (size_t)(n / 2) * sizeof(C<T>));
+        if (rc != DSPMI_OK) return rc;
+        hipLaunchKernelGGL(c2r_merge_kernel<T>, dim3(ew_grid(batch * (n / 2), pl->num_cu)), dim3(256), 0, s,
+                           static_cast<const C<T> *>(in), static_cast<C<T> *>(pl->work[1]),
+                           static_cast<const C<T> *>(pl->tw_n), n, batch);
+        DSPMI_HIP(hipGetLastError());
+        return c2c_typed<T>(pl->half_plan, pl->work[1], out, batch, 1, s);
     }
     int rc = ensure_work(pl, 1, 2 * batch * (size_t)n * sizeof(C<T>));
     if (rc != DSPMI_OK) return rc;
@@ -585,6 +609,7 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n, n, precision);
     if (rc == DSPMI_OK && kh) rc = upload_twiddles(&pl->tw_half, n / 2, precision);
     if (rc == DSPMI_OK && kM) rc = precision == DSPMI_F64 ? setup_bluestein<double>(pl) : setup_bluestein<float>(pl);
+    if (rc == DSPMI_OK && kM && n % 2 == 0 && n >= 4 && !is_pow2(n / 2)) rc = dspmi_fft_create(&pl->half_plan, n / 2, precision, device);
     (void)hipSetDevice(prev);
     if (rc != DSPMI_OK) {
         dspmi_fft_destroy(pl);
@@ -597,6 +622,7 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
 int dspmi_fft_destroy(dspmi_fft_t plan)
 {
     if (!plan) return DSPMI_OK;
+    if (plan->half_plan) (void)dspmi_fft_destroy(plan->half_plan);
     void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1], plan->work[2], plan->work[3]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

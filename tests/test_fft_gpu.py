@@ -324,3 +324,23 @@ def test_any_length_one_kernel_form(n, batch, monkeypatch):
         assert rel_l2(fwd[f], want) <= TOL_FFT, (f, rel_l2(fwd[f], want))
         assert rel_l2(fwd_c[f], want) <= TOL_FFT
         assert rel_l2(bwd[f], np.conj(np.fft.fft(np.conj(zz)))) <= TOL_FFT
+
+
+@pytest.mark.parametrize("dtype,n,batch", [("f32", 6, 5), ("f32", 480, 9), ("f32", 481, 4), ("f32", 1000, 33), ("f32", 6000, 3),
+                                           ("f64", 482, 7), ("f64", 1000, 2)])
+def test_batched_real_transforms_any_length(dtype, n, batch):
+    """r2c / c2r of lengths that are not powers of two, batched on the device: even lengths through
+    the half-length complex plan, odd ones through the full complex transform."""
+    rng = np.random.default_rng(n + batch)
+    rt = torch.float32 if dtype == "f32" else torch.float64
+    tol = TOL_FFT if dtype == "f32" else TOL_F64
+    x = rng.uniform(-1, 1, (batch, n))
+    plan = dsp_amd.FftPlan(n, dtype)
+    xd = torch.from_numpy(x).to(rt).cuda()
+    bins = plan.r2c(xd)
+    back = plan.c2r(bins).cpu().numpy() / n
+    got = bins.cpu().numpy()
+    for f in sorted({0, batch // 2, batch - 1}):
+        xf = xd[f].double().cpu().numpy()
+        assert rel_l2(got[f], oracle.fft_r2c(xf)) <= tol, (f, rel_l2(got[f], oracle.fft_r2c(xf)))
+        assert rel_l2(back[f], xf) <= tol
