@@ -313,6 +313,32 @@ __device__ __forceinline__ void run_passes(C<T> *v, C<T> *lds, const C<T> *tw1, 
 
 template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
 
+// Workgroups to launch for `nfb` frame-blocks when `resident` fit the chip at once.  A grid of
+// just the resident set, each workgroup looping over many frame-blocks, streams 5-8 % slower than
+// a grid the dispatcher keeps refilling: the memory-bound kernels run fastest when a workgroup
+// handles only as many frame-blocks as it takes to amortise its set-up (`iters`; measured optimum
+// ~2.7 for the 8 KB twiddle table of 1024 points, 1 where the tables are a few hundred bytes),
+// the compute-bound ones with a few times the resident set.  DSPMI_GRIDX=<k> forces
+// resident * k for experiments.
+inline size_t grid_for(size_t nfb, size_t resident, double iters)
+{
+    size_t grid = resident;
+    const char *env = getenv("DSPMI_GRIDX");
+    if (env && atoi(env) > 0) {
+        grid *= (size_t)atoi(env);
+    } else if (iters > 0) {
+        const size_t g = (size_t)((double)nfb / iters + 0.999);
+        if (g > grid) grid = g;
+    }
+    return grid > nfb ? nfb : grid;
+}
+
+// Frame-blocks per workgroup that amortise the LDS twiddle table set-up (see grid_for).
+constexpr double table_iters(size_t tw_entries, size_t esz)
+{
+    return tw_entries * esz > 3072 ? (double)(tw_entries * esz) / 3072.0 : 1.0;
+}
+
 // The fused overlap-save kernel is latency-bound and its occupancy LDS-bound (frame images plus
 // one twiddle table per workgroup): eight 1024-point frames per workgroup share the table, which
 // fits 16 waves on a CU where four-frame workgroups fit 12.
@@ -890,8 +916,8 @@ int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_
     size_t per_cu = (160 * 1024) / lds;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
-    size_t grid = (size_t)num_cu * per_cu;
-    if (grid > nfb) grid = nfb;
+    // compute-bound: a few times the resident set (1.11 -> 1.08 ms at N = 1024; larger grids are slower)
+    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, N == 1024 ? (double)nfb / (4.0 * num_cu * per_cu) : 0.0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, a, static_cast<const C<float> *>(tw));
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
@@ -1012,8 +1038,7 @@ int launch_bluestein(const void *in, void *out, const void *chirp, const void *f
     size_t per_cu = (160 * 1024) / lds;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
-    size_t grid = (size_t)num_cu * per_cu;
-    if (grid > nfb) grid = nfb;
+    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, 0.0);  // compute-bound: the resident set measured fastest
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), static_cast<C<T> *>(out),
                        static_cast<const C<T> *>(chirp), static_cast<const C<T> *>(filt), static_cast<const C<T> *>(tw), n, batch,
                        backward);
@@ -1056,12 +1081,12 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     }
     if (batch == 0) return DSPMI_OK;
     const size_t nfb = (batch + FPB - 1) / FPB;
-    // one resident set of workgroups, each looping over frames
+    // workgroups that fit a CU at once
     size_t per_cu = lds ? (160 * 1024) / lds : 8;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
-    // Wave-private frames with the next frame's loads already in flight stream fastest with two
-    // workgroups per CU (measured 5.47 TB/s against 5.21 with three); DSPMI_FFT_BPC overrides.
+    // The prefetching variant (persistent grid, next frame's loads in flight) streams fastest with
+    // two workgroups per CU (5.47 TB/s against 5.21 with three); DSPMI_FFT_BPC overrides.
     size_t cap = (PREFETCH && NT <= 64) ? 2 : per_cu;
     {
         const char *env = getenv("DSPMI_FFT_BPC");
@@ -1073,12 +1098,14 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
         lds_req = (160 * 1024) / per_cu - 512;  // inflated request: no more than `cap` fit a CU
         if (lds_req < lds) lds_req = lds;
     }
-    size_t grid = (size_t)num_cu * per_cu;
+    // short frames staged through LDS and the prefetching variant keep a persistent grid; the rest
+    // launch one workgroup per few frame-blocks (see grid_for)
+    double iters = (staged || PREFETCH || !lds) ? 0.0 : table_iters(tw_entries, sizeof(C<T>));
     {
-        const char *env = getenv("DSPMI_FFT_GRIDX");
-        if (env && atoi(env) > 0) grid *= atoi(env);
+        const char *env = getenv("DSPMI_FFT_ITERS");  // experiment: frame-blocks per workgroup
+        if (env && atof(env) > 0) iters = atof(env);
     }
-    if (grid > nfb) grid = nfb;
+    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, iters);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds_req, s, static_cast<const C<T> *>(in),
                        static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), batch, backward);
     DSPMI_HIP(hipGetLastError());
@@ -1108,8 +1135,8 @@ int launch_r2c(const void *in, void *out, const void *tw, const void *tw2n, size
     size_t per_cu = (160 * 1024) / lds;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
-    size_t grid = (size_t)num_cu * per_cu;
-    if (grid > nfb) grid = nfb;
+    // frames inside one wave: as the complex kernel (n = 1024: 0.50 -> 0.43 ms per 2^28 samples); longer frames measured flat
+    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, NT <= 64 ? table_iters(lds_twiddle_entries(TW, R0, R1, R2, R3, N), sizeof(C<T>)) : 0.0);
     hipLaunchKernelGGL(epilogue == 1 ? k1 : k2, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), out,
                        static_cast<const C<T> *>(tw), static_cast<const C<T> *>(tw2n), batch, nbin, mode, scale, pcm);
     DSPMI_HIP(hipGetLastError());
@@ -1133,8 +1160,8 @@ int launch_c2r(const void *in, void *out, const void *tw, const void *tw2n, size
     size_t per_cu = (160 * 1024) / lds;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
-    size_t grid = (size_t)num_cu * per_cu;
-    if (grid > nfb) grid = nfb;
+    // a few times the resident set for frames inside one wave (0.445 -> 0.42 ms); longer frames are fastest persistent
+    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, NT <= 64 ? (double)nfb / (4.0 * num_cu * per_cu) : 0.0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<T> *>(in), static_cast<C<T> *>(out),
                        static_cast<const C<T> *>(tw), static_cast<const C<T> *>(tw2n), batch);
     DSPMI_HIP(hipGetLastError());
@@ -1177,7 +1204,7 @@ const FftEntry kF32[] = {
     F32S(2, 1, 2, 1, 1, 1),         F32S(4, 1, 4, 1, 1, 1),         F32S(8, 1, 8, 1, 1, 1),
     F32S(16, 1, 16, 1, 1, 1),       F32S(32, 2, 16, 2, 1, 1),       F32S(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
-    F32P(1024, 64, 16, 16, 4, 1),   F32P(2048, 128, 16, 16, 8, 1),   F32T(4096, 256, 16, 16, 16, 1, 2),
+    F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),    F32T(4096, 256, 16, 16, 16, 1, 2),
     F32T(8192, 512, 16, 16, 16, 2, 3),
     {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 3>,
      "fft_f32_n16384_r16x16x16x4_splittw", nullptr, nullptr},
@@ -1195,13 +1222,16 @@ const FftEntry kF32Alt1024[] = {
     {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 1, false>, "fft_f32_n1024_r16x16x4_twreg", nullptr, nullptr},
     {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, false, 3>, "fft_f32_n1024_r16x16x4_twlds_nopf", nullptr, nullptr},
     {1024, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false>, launch_c2c<float, 1024, 64, 16, 8, 8, 1, 2, false, 3>, "fft_f32_n1024_r16x8x8_twlds", nullptr, nullptr},
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 0, false>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 0, false, 3>, "fft_f32_n1024_r16x16x4_twglobal", nullptr, nullptr},
+    // persistent grid, next frame's loads issued before the current frame is computed, two workgroups per CU
+    {1024, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true>, launch_c2c<float, 1024, 64, 16, 16, 4, 1, 2, true, 3>, "fft_f32_n1024_r16x16x4_pf", nullptr, nullptr},
 };
 
 const FftEntry *find_entry(unsigned n, int precision)
 {
     if (n == 1024 && precision == DSPMI_F32) {
         const char *env = getenv("DSPMI_FFT_VARIANT");
-        if (env && atoi(env) >= 1 && atoi(env) <= 3) return &kF32Alt1024[atoi(env) - 1];
+        if (env && atoi(env) >= 1 && atoi(env) <= 5) return &kF32Alt1024[atoi(env) - 1];
     }
     const FftEntry *tab = precision == DSPMI_F64 ? kF64 : kF32;
     const size_t cnt = precision == DSPMI_F64 ? sizeof(kF64) / sizeof(kF64[0]) : sizeof(kF32) / sizeof(kF32[0]);

@@ -492,10 +492,8 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
     const unsigned seg = p.nhp < (unsigned)kMfmaSeg ? p.nhp : (unsigned)kMfmaSeg;
     size_t lds = mfma_lds_floats(TILE, seg) * sizeof(float);
     {
-        // Resident workgroups per CU are capped by inflating the LDS request.  A short
-        // filter is an HBM-bound stream, and the stream is measurably faster with 2-3
-        // workgroups (8-12 waves) per CU than with 8; a long filter is MFMA-bound and
-        // wants every wave it can get to cover staging and stores.
+        // Resident workgroups per CU can be capped by inflating the LDS request
+        // (DSPMI_FIR_BPC, for experiments); both regimes measured fastest with all eight.
         const char *env = getenv("DSPMI_FIR_BPC");
         const int bpc = env && atoi(env) > 0 ? atoi(env) : bpc_default;
         const size_t want = (160 * 1024) / bpc - 512;
@@ -507,9 +505,17 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
     if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
     p.ntiles_total = (unsigned)tiles;
     // a few thousand workgroups keep all 256 CUs busy for several rounds; beyond that,
-    // longer walks amortise the pipeline fill of each workgroup
+    // longer walks amortise the pipeline fill of each workgroup.  A short filter is an HBM-bound
+    // stream, which runs fastest with many short-lived workgroups: two tiles each (16 taps,
+    // 512 x 2^20 samples: 5.82 TB/s against 5.50 with eight tiles and two workgroups per CU).
     unsigned tpb = (unsigned)(tiles / 16384);
     p.tiles_per_block = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
+    const unsigned short_cap = p.nhp <= 32 ? 2 : 4;  // 33..64 taps: four tiles measured best
+    if (p.nhp <= 64 && p.tiles_per_block > short_cap) p.tiles_per_block = short_cap;
+    {
+        const char *env = getenv("DSPMI_FIR_TPB");  // experiment knob
+        if (env && atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
+    }
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
     auto k_small = fir_mfma_kernel<(TILE + 256 + 255) / 256, TPW>;      // segments up to 256 taps
     auto k_large = fir_mfma_kernel<(TILE + kMfmaSeg + 255) / 256, TPW>;  // up to kMfmaSeg taps
@@ -527,7 +533,7 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
 int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 {
     // four 256-output tiles per wave (eight measured no faster at 127 taps)
-    return launch_mfma_t<4>(p, nchan, p.nhp <= 64 ? 2 : 8, stream);
+    return launch_mfma_t<4>(p, nchan, 8, stream);
 }
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
