@@ -916,8 +916,8 @@ int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_
     size_t per_cu = (160 * 1024) / lds;
     if (per_cu > 2048 / BT) per_cu = 2048 / BT;
     if (per_cu < 1) per_cu = 1;
-    // compute-bound: a few times the resident set (1.11 -> 1.08 ms at N = 1024; larger grids are slower)
-    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, N == 1024 ? (double)nfb / (4.0 * num_cu * per_cu) : 0.0);
+    // compute-bound: four times the resident set (N = 1024: 1.11 -> 1.08 ms, 8192: 1.94 -> 1.82; larger grids are slower)
+    const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, (double)nfb / (4.0 * num_cu * per_cu));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds, s, a, static_cast<const C<float> *>(tw));
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
