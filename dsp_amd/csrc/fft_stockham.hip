@@ -330,7 +330,8 @@ inline size_t grid_for(size_t nfb, size_t resident, double iters)
         const size_t g = (size_t)((double)nfb / iters + 0.999);
         if (g > grid) grid = g;
     }
-    return grid > nfb ? nfb : grid;
+    if (grid > nfb) grid = nfb;
+    return grid > 0x7fffffffu ? 0x7fffffffu : grid;  // the kernels stride by the grid: any size covers every frame
 }
 
 // Frame-blocks per workgroup that amortise the LDS twiddle table set-up (see grid_for).
