@@ -1183,12 +1183,6 @@ typedef dspmi::FftKernel FftEntry;
 #define F32S(N, NT, A, B, C_, D)                                                                            \
     {N, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, false, 3>, \
      "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr, nullptr}
-// same, with the next frame's global loads issued before the current frame is computed
-// (frames that span several waves keep few frames in flight per CU otherwise)
-#define F32P(N, NT, A, B, C_, D)                                                                          \
-    {N, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 0>, launch_c2c<float, N, NT, A, B, C_, D, 2, true, 3>, \
-     "fft_f32_n" #N "_r" #A "x" #B "x" #C_ "x" #D "_pf", launch_r2c<float, N, NT, A, B, C_, D, 2>, \
-     launch_c2r<float, N, NT, A, B, C_, D, 2>}
 // long frames: full twiddle tables hold about N entries whatever the radix order -- as much LDS
 // as the frame itself -- so the complex kernel builds its twiddles from two short tables and
 // twice as many workgroups fit a CU (4096: 4.7 -> 5.2 TB/s, 8192: 3.6 -> 5.1, 16384: 2.8 -> 3.8).
