@@ -119,16 +119,22 @@ def timed(fn, steps, warmup, world):
 
 def make_fft(args, rank):
     n = 1024
-    z = torch.view_as_complex(uniform((args.frames, n, 2), 0xD5B0 + 2 + rank, "cuda"))
-    out = torch.empty_like(z)
+    # Input and output are the two halves of one allocation.  The kernel's rate depends on where
+    # the two streams fall relative to each other in the memory-channel mapping (period 32 MiB:
+    # 5.85 TB/s at the best offsets, 5.35 at the worst, tools/fft_offsets.py); two separate
+    # allocations land anywhere, which made the figure vary from process to process.
+    both = torch.empty((2, args.frames, n, 2), dtype=torch.float32, device="cuda")
+    both[0].uniform_(-1.0, 1.0, generator=torch.Generator(device="cuda").manual_seed(0xD5B0 + 2 + rank))
+    z = torch.view_as_complex(both[0])
+    out = torch.view_as_complex(both[1])
     plan = dsp_amd.FftPlan(n, "f32")
     flop_per_frame = 5.0 * n * math.log2(n)     # nominal radix-2 count
     bytes_per_frame = 2.0 * n * 8               # read once + write once
     info = dict(kernel=plan.variant, units=args.frames, unit_name="frames", n=n,
                 flop_per_unit=flop_per_frame, bytes_per_unit=bytes_per_frame, bound="hbm",
                 samples_per_unit=n,
-                workload="batched c2c f32 FFT, N=1024, %d frames per GPU, out of place" % args.frames)
-    return (lambda: plan.c2c(z, dsp_amd.FORWARD, out=out)), info, (plan, z, out)
+                workload="batched c2c f32 FFT, N=1024, %d frames per GPU, out of place (output buffer directly behind the input)" % args.frames)
+    return (lambda: plan.c2c(z, dsp_amd.FORWARD, out=out)), info, (plan, z, out, both)
 
 
 def sinc_taps(nh):
@@ -429,10 +435,11 @@ def main():
             if args.workload == ("fir%d%s" % (nh, "_direct" if direct else "")):
                 continue
             f2, i2, k2 = make_fir(args, rank, nh, direct)
-            d2, ms2 = timed(f2, 5, 2, 1)
+            nsec = 10
+            d2, ms2 = timed(f2, nsec, 3, 1)
             secondary.append({"workload": i2["workload"],
-                              "gsamples_per_s": round(i2["units"] * 5 / d2 / 1e9, 2),
-                              "gflops": round(i2["flop_per_unit"] * i2["units"] * 5 / d2 / 1e9, 1),
+                              "gsamples_per_s": round(i2["units"] * nsec / d2 / 1e9, 2),
+                              "gflops": round(i2["flop_per_unit"] * i2["units"] * nsec / d2 / 1e9, 1),
                               "roofline": roofline(i2, ms2)})
             del f2, k2
             torch.cuda.empty_cache()
