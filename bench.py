@@ -119,10 +119,9 @@ def timed(fn, steps, warmup, world):
 
 def make_fft(args, rank):
     n = 1024
-    # Input and output are the two halves of one allocation.  The kernel's rate depends on where
-    # the two streams fall relative to each other in the memory-channel mapping (period 32 MiB:
-    # 5.85 TB/s at the best offsets, 5.35 at the worst, tools/fft_offsets.py); two separate
-    # allocations land anywhere, which made the figure vary from process to process.
+    # Input and output are the two halves of one allocation: the same placement in every process
+    # (the kernel visits the frames from two fronts so that its rate does not depend on the
+    # distance between the buffers, tools/fft_offsets.py; this keeps the rest equal too).
     both = torch.empty((2, args.frames, n, 2), dtype=torch.float32, device="cuda")
     both[0].uniform_(-1.0, 1.0, generator=torch.Generator(device="cuda").manual_seed(0xD5B0 + 2 + rank))
     z = torch.view_as_complex(both[0])
