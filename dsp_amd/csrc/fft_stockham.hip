@@ -347,7 +347,7 @@ template <int N, int NT> constexpr int ols_block_threads() { return N == 1024 ? 
 
 // flag bits of the c2c kernel
 constexpr int kFftBackward = 1;   // conj . forward . conj
-constexpr int kFftTwoFronts = 2;  // frame-blocks visited from two fronts 16 MiB apart (see the frame loop)
+// bits 1-2: log2 of the number of fronts the frame-blocks are visited from (see the frame loop)
 
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T> *in, C<T> *out,
@@ -494,17 +494,17 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T>
     } else {
         for (size_t fb0 = blockIdx.x; fb0 < nfb; fb0 += gridDim.x) {
             size_t fb = fb0;
-            if (flags & kFftTwoFronts) {
+            if (const unsigned lf = (flags >> 1) & 3) {
                 // Launched as a moving front, the kernel's rate depends on the distance between
                 // the two buffers modulo the 32 MiB period of the memory-channel mapping (5.35 to
-                // 5.9 TB/s at N = 1024).  Workgroups therefore alternate between two fronts half a
-                // period apart inside every full 32 MiB group of frame-blocks: reads and writes
-                // then meet at both phases at once and the rate is 5.8-5.9 wherever the buffers are.
+                // 5.9 TB/s at N = 1024).  Workgroups therefore alternate between 2^lf fronts spread
+                // evenly over every full 32 MiB group of frame-blocks: reads and writes then meet
+                // at several phases at once and the rate no longer depends on where the buffers are.
                 constexpr size_t G = ((size_t)32 << 20) / (FPB * N * sizeof(C<T>));
                 const size_t g0 = fb0 / G * G;
                 if (g0 + G <= nfb) {
                     const size_t i = fb0 - g0;
-                    fb = g0 + ((i & 1) ? G / 2 + i / 2 : i / 2);
+                    fb = g0 + (i & ((1u << lf) - 1)) * (G >> lf) + (i >> lf);
                 }
             }
             C<T> v[P];
@@ -1127,8 +1127,9 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     const size_t grid = grid_for(nfb, (size_t)num_cu * per_cu, iters);
     int flags = backward ? kFftBackward : 0;
     {
-        const char *env = getenv("DSPMI_FFT_FRONTS");  // A/B knob: 1 = a single front
-        if (iters > 0 && !(env && atoi(env) == 1)) flags |= kFftTwoFronts;
+        const char *env = getenv("DSPMI_FFT_FRONTS");  // A/B knob: 1, 2, 4 or 8 fronts
+        const int fronts = env && atoi(env) > 0 ? atoi(env) : 2;
+        if (iters > 0) flags |= (fronts >= 8 ? 3 : fronts >= 4 ? 2 : fronts >= 2 ? 1 : 0) << 1;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), lds_req, s, static_cast<const C<T> *>(in),
                        static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), batch, flags);
