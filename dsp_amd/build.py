@@ -61,7 +61,8 @@ def _compile(job):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(HERE, "..", "include", "dspmi.h"))
+    inc = os.path.join(HERE, "..", "include")   # the whole public contract: dspmi.h, the FFTW subset, the name map
+    headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     jobs, objs = [], []
     for name, flags in SOURCES.items():
         src = os.path.join(CSRC, name)

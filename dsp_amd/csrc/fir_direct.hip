@@ -237,7 +237,13 @@ constexpr unsigned mfma_lds_floats(unsigned tile, unsigned seglen)
 // input window of unit u+1 is already on its way from HBM into registers, and
 // is written to LDS once the loop is done (one LDS buffer, two barriers).
 // NIT = staging registers per lane = ceil((tile + segment - 1) / 256).
-template <int NIT, int TPW>
+// BLOCKSUM: an f32 chain of n products carries a rounding error that grows like sqrt(n)
+// (measured against the double sum of fft/src/main.c:193-204: 1.8e-7 at 127 taps, 7e-7 at
+// 2049, 1.5e-6 at 8191).  Long filters therefore sum in blocks: every kBlockGroups * 16 taps
+// the chain's accumulators are added to a second set and start again from zero, which holds
+// every tap count to the error of a 500-tap chain (about 4e-7).
+constexpr int kBlockGroups = 31;
+template <int NIT, int TPW, bool BLOCKSUM>
 __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 {
     constexpr int kMfmaTile = mfma_tile(TPW);
@@ -299,9 +305,11 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
         d.xrow = p.x + (size_t)chan * p.x_stride;
         d.hrow = p.hist ? p.hist + (size_t)chan * p.hist_stride : nullptr;
         // A buffer load returns 0 for any offset outside [0, nx*4): exactly the zero extension
-        // on both sides of the row.  History, the conv1 quirk and rows too long for a 32-bit
-        // byte offset are staged by the checked loop in commit() instead.
-        d.plain = nx <= (1l << 29) && !(d.hrow && d.sbase < 0) && !(drop_first && d.sbase <= 0);
+        // on both sides of the row.  History, the conv1 quirk and windows whose byte offsets do
+        // not fit 32 bits (a long row, or a zero tail far past a short one) are staged by the
+        // checked loop in commit() instead.
+        d.plain = nx <= (1l << 29) && d.sbase + d.nstage <= (1l << 29) && !(d.hrow && d.sbase < 0) &&
+                  !(drop_first && d.sbase <= 0);
         return d;
     };
 
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
     commit(next, true);
     __syncthreads();
 
-    f32x4 acc[TPW];
+    f32x4 acc[TPW], tot[BLOCKSUM ? TPW : 1];
     for (long unit = 0; unit < nunits; unit++) {
         const Unit cur = next;
         const bool more = unit + 1 < nunits;
@@ -407,22 +415,51 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
             }
         };
         int nu = (seglen + 16) / 16;  // >= 2
-        if (cur.seg0 == 0) group(ap, bp, true);
-        else group(ap, bp, false);
-        ap += 16;
-        bp += kRow;
-        nu--;
-        for (; nu >= 3; nu -= 3) {
-            group(ap, bp, false);
-            group(ap + 16, bp + kRow, false);
-            group(ap + 32, bp + 2 * kRow, false);
-            ap += 48;
-            bp += 3 * kRow;
-        }
-        for (; nu > 0; nu--) {
-            group(ap, bp, false);
+        if constexpr (BLOCKSUM) {
+            if (cur.seg0 == 0) {
+#pragma unroll
+                for (int q = 0; q < TPW; q++) tot[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            while (nu > 0) {
+                int take = nu < kBlockGroups ? nu : kBlockGroups;
+                nu -= take;
+                group(ap, bp, true);
+                ap += 16;
+                bp += kRow;
+                take--;
+                for (; take >= 3; take -= 3) {
+                    group(ap, bp, false);
+                    group(ap + 16, bp + kRow, false);
+                    group(ap + 32, bp + 2 * kRow, false);
+                    ap += 48;
+                    bp += 3 * kRow;
+                }
+                for (; take > 0; take--) {
+                    group(ap, bp, false);
+                    ap += 16;
+                    bp += kRow;
+                }
+#pragma unroll
+                for (int q = 0; q < TPW; q++) tot[q] += acc[q];
+            }
+        } else {
+            if (cur.seg0 == 0) group(ap, bp, true);
+            else group(ap, bp, false);
             ap += 16;
             bp += kRow;
+            nu--;
+            for (; nu >= 3; nu -= 3) {
+                group(ap, bp, false);
+                group(ap + 16, bp + kRow, false);
+                group(ap + 32, bp + 2 * kRow, false);
+                ap += 48;
+                bp += 3 * kRow;
+            }
+            for (; nu > 0; nu--) {
+                group(ap, bp, false);
+                ap += 16;
+                bp += kRow;
+            }
         }
 
         if (last_seg) {
@@ -434,12 +471,13 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 #pragma unroll
             for (int q = 0; q < TPW; q++) {
                 const long o0 = tile_start + wave * (TPW * 256) + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4);
+                const f32x4 res = BLOCKSUM ? tot[q] : acc[q];
                 if (y_vec && o0 + 4 <= (long)p.nxx) {
-                    __builtin_nontemporal_store(acc[q], reinterpret_cast<f32x4 *>(&yrow[o0]));
+                    __builtin_nontemporal_store(res, reinterpret_cast<f32x4 *>(&yrow[o0]));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        if (o0 + r < (long)p.nxx) yrow[o0 + r] = acc[q][r];
+                        if (o0 + r < (long)p.nxx) yrow[o0 + r] = res[r];
                 }
             }
         }
@@ -517,8 +555,8 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
         if (env && atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
     }
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
-    auto k_small = fir_mfma_kernel<(TILE + 256 + 255) / 256, TPW>;      // segments up to 256 taps
-    auto k_large = fir_mfma_kernel<(TILE + kMfmaSeg + 255) / 256, TPW>;  // up to kMfmaSeg taps
+    auto k_small = fir_mfma_kernel<(TILE + 256 + 255) / 256, TPW, false>;      // segments up to 256 taps
+    auto k_large = fir_mfma_kernel<(TILE + kMfmaSeg + 255) / 256, TPW, true>;  // up to kMfmaSeg taps, summed in blocks
     static dspmi::PerDeviceOnce attr;
     if (attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_small), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -547,9 +585,13 @@ int launch(const FirParams<T> &p, unsigned nchan, hipStream_t stream)
     const unsigned seg = p.nhp < (unsigned)kSeg ? p.nhp : (unsigned)kSeg;
     const size_t lds = lds_elems<R>(TILE + seg + 8) * sizeof(T);
     auto kern = fir_direct_kernel<T, R, G, NHB, kSeg, EXACT, DESC, PCM>;
-    if (lds > 48 * 1024)
+    static dspmi::PerDeviceOnce attr;  // one per instantiation; the limit covers every tap count
+    constexpr size_t lds_max = lds_elems<R>(TILE + kSeg + 8) * sizeof(T);
+    if (lds_max > 48 * 1024 && attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr.mark();
+    }
     const unsigned long long blocks = (unsigned long long)p.tiles_per_chan * nchan;
     if (blocks == 0) return DSPMI_OK;
     if (blocks > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu workgroups exceed the grid limit", blocks);
@@ -584,11 +626,12 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
     if (precision == DSPMI_F64) {
         pl->variant = V_F64_EXACT;
     } else {
-        const char *force = getenv("DSPMI_FIR_VARIANT");  // A/B knob: valu | mfma | (default: automatic)
-        if (force && !strcmp(force, "valu")) pl->variant = nh <= 32 ? V_F32_SHORT : V_F32_LONG;
-        else pl->variant = V_F32_MFMA;
+        // A/B knob: "valu" or "mfma" pins that direct kernel; any other value means automatic
+        const char *env = getenv("DSPMI_FIR_VARIANT");
+        const bool valu = env && !strcmp(env, "valu"), pinned = valu || (env && !strcmp(env, "mfma"));
+        pl->variant = valu ? (nh <= 32 ? V_F32_SHORT : V_F32_LONG) : V_F32_MFMA;
         if constexpr (sizeof(T) == 4) {
-            if (!force && nh >= kOlsMinTaps && nh <= 8192) {
+            if (!pinned && nh >= kOlsMinTaps && nh <= 8192) {
                 // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
                 // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384
                 unsigned n = 1024;

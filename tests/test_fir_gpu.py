@@ -106,6 +106,62 @@ def test_f32_parity(nh, nx, nchan, fir_path):
             assert np.all(got[:, -1] == 0)  # the extra element of fft/src/main.c:190
 
 
+def block_errors(got, want, blk=4096):
+    """Relative L2 error of every 4096-sample output block of one row (a last block of fewer
+    than 1024 samples is counted with the one before it)."""
+    edges = list(range(0, len(want), blk)) + [len(want)]
+    if len(edges) > 2 and edges[-1] - edges[-2] < blk // 4:
+        del edges[-2]
+    return [rel_l2(got[a:b], want[a:b]) for a, b in zip(edges, edges[1:])]
+
+
+@pytest.mark.parametrize("nh", [2049, 4096, 4097, 8191])
+@pytest.mark.parametrize("nx,nchan", [(5000, 2), (12345, 1), (20481, 2)])
+def test_f32_direct_kernel_beyond_one_tap_segment(nh, nx, nchan, monkeypatch):
+    """More than 2048 taps: the direct MFMA kernel walks the taps in LDS-sized segments, carrying
+    its accumulators from one to the next and re-staging the tap table each time -- the
+    8191-tap direct sum of fft/src/main.c:193-204.  Pinned, because the plan alone would
+    pick overlap-save; checked per 4096-sample block, with and without the nx + nh tail."""
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")
+    rng = np.random.default_rng(nh + nx)
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    for nxx in (nx, nx + nh):
+        got, variant = run_f32(x, h, nxx)
+        assert "mfma" in variant
+        want = oracle.fir_batch_f32(x, h, nxx)
+        for c in range(nchan):
+            worst = max(block_errors(got[c, :nx + nh - 1], want[c, :nx + nh - 1]))
+            assert worst <= TOL_FIR, (variant, nh, nx, nxx, c, worst)
+        if nxx == nx + nh:
+            assert np.all(got[:, -1] == 0)
+
+
+@pytest.mark.parametrize("nh", [2049, 8191])
+def test_f32_direct_kernel_long_filter_with_history(nh, monkeypatch):
+    """The same segments with carried history: a long row cut in three chunks gives the row's
+    outputs (the window of a tile then reaches into hist for several segments)."""
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")
+    rng = np.random.default_rng(nh)
+    nchan, chunk = 2, 9000
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (nchan, 3 * chunk)).astype(np.float32)
+    whole = oracle.fir_batch_f32(x, h, 3 * chunk)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert "mfma" in plan.variant
+    xd = torch.from_numpy(x).cuda()
+    hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
+    outs = []
+    for k in range(3):
+        outs.append(plan.exec(xd[:, k * chunk:(k + 1) * chunk], chunk, hist=hist).cpu().numpy())
+        lo = (k + 1) * chunk - (nh - 1)
+        hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
+        hist[:, max(0, -lo):] = xd[:, max(0, lo):(k + 1) * chunk]
+    got = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert max(block_errors(got[c], whole[c])) <= TOL_FIR, (nh, c)
+
+
 def test_f32_reference_taps_and_tone(golden_dir):
     g = np.load(os.path.join(golden_dir, "tone_fir.npz"))
     tone = g["tone"].astype(np.float32)[None, :]

@@ -42,6 +42,34 @@ def test_fir_row_longer_than_2_31_samples(nh, path, nx, monkeypatch):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("nx", [1000, (1 << 29) - 7])
+def test_fir_long_zero_tail_behind_a_short_row(nx, monkeypatch):
+    """Outputs far past the input (nxx > 2^30 samples behind a row of at most 2^29): tiles whose
+    window starts beyond 2^30 samples have byte offsets that do not fit 32 bits; they must
+    produce zeros, not samples from the start of the row."""
+    if torch.cuda.mem_get_info()[0] < 16 << 30:
+        pytest.skip("needs 16 GiB of free device memory")
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")
+    nh = 16
+    h = np.asarray(oracle.TAPS16, dtype=np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    nxx = (1 << 31) + 4096 + 5
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand((1, nx), device="cuda", generator=g) * 2 - 1
+    y = torch.full((1, nxx), 7.0, device="cuda")
+    plan.exec(x, nxx, y=y)
+    torch.cuda.synchronize()
+    head = min(nx, 5000)
+    want = oracle.fir_batch_f32(x[:, :head].cpu().numpy(), h, head)[0]
+    assert rel_l2(y[0, :head].cpu().numpy(), want) <= 1e-6
+    tail = x[0, nx - 64:].cpu().numpy()
+    want_tail = oracle.fir_batch_f32(tail[None, :], h, 64 + nh)[0][64:]
+    np.testing.assert_allclose(y[0, nx:nx + nh].cpu().numpy(), want_tail, rtol=0, atol=1e-6)
+    assert not bool(y[0, nx + nh:].any())     # everything past the filter's reach is an empty sum
+    del x, y
+    torch.cuda.empty_cache()
+
+
 def test_c2c_batch_of_more_than_2_32_points():
     if torch.cuda.mem_get_info()[0] < 80 << 30:
         pytest.skip("needs 80 GiB of free device memory")

@@ -8,16 +8,36 @@ import oracle
 
 pytestmark = pytest.mark.gpu
 
-# f32 FFT-domain filtering: the forward + backward transform error is relative to the norm of
-# the transformed block (input x taps), not to the output it lands on, so the bound is the FFT
-# tolerance of the path, 1e-5, against max(|output row|, |taps| * |input row|) -- a start-up
-# transient that is itself ~1e-6 of the input cannot be resolved to 1e-5 of its own size.
-TOL_OLS = 1e-5
+# The bound of the FIR path, 1e-6 relative L2 per 4096-sample output block, holds for every block
+# of steady-state output.  The blocks that contain the first nh - 1 outputs are a start-up
+# transient: with windowed-sinc taps they are sums over the filter's tiny outer taps only, far
+# smaller than the signal, while the rounding error of a transform is relative to what goes
+# through it (the whole input block times the whole filter).  Those blocks are held to the same
+# ABSOLUTE error as a steady-state block: 1e-6 of |taps| * |input block|, the norm a block of
+# steady-state output of white input has.
+TOL_FIR = 1e-6
+BLK = 4096
 
 
 def rel_l2(got, want):
     den = np.linalg.norm(want)
     return np.linalg.norm(np.asarray(got, np.float64) - want) / den if den > 0 else np.linalg.norm(got)
+
+
+def check_blocks(got, want, x, h, tag):
+    """got/want/x: one row.  Returns the worst steady-state block error."""
+    hn = np.linalg.norm(h.astype(np.float64))
+    worst = 0.0
+    for lo in range(0, len(want), BLK):
+        g, w = got[lo:lo + BLK].astype(np.float64), want[lo:lo + BLK]
+        err = np.linalg.norm(g - w)
+        if lo >= len(h) - 1:
+            assert err <= TOL_FIR * np.linalg.norm(w), (tag, lo, err / np.linalg.norm(w))
+            worst = max(worst, err / np.linalg.norm(w))
+        else:
+            scale = hn * np.linalg.norm(x[lo:lo + BLK].astype(np.float64))
+            assert err <= TOL_FIR * max(np.linalg.norm(w), scale), (tag, lo, "start-up", err / scale)
+    return worst
 
 
 @pytest.mark.parametrize("nh,fft_n", [(16, 64), (127, 1024), (300, 2048), (1000, 4096), (8191, 16384), (8191, 0), (33, 0)])
@@ -31,26 +51,46 @@ def test_ols_matches_oracle(nh, fft_n, nx, nchan):
     y = plan.exec(torch.from_numpy(x).cuda()).cpu().numpy()
     want = oracle.fir_batch_f32(x, h, nx)
     for c in range(nchan):
-        scale = np.linalg.norm(h.astype(np.float64)) * np.linalg.norm(x[c].astype(np.float64))
-        assert np.linalg.norm(y[c] - want[c]) <= TOL_OLS * max(np.linalg.norm(want[c]), scale), (nh, fft_n, nx, c)
+        check_blocks(y[c], want[c], x[c], h, (nh, fft_n, nx, c))
 
 
-def test_ols_history_and_agreement_with_direct_kernel():
+@pytest.mark.parametrize("fft_n", [0, 16384, 32768])
+def test_ols_8191_taps_on_the_bench_inputs(fft_n):
+    """BASELINE config 4's filter (8191 windowed-sinc taps) on uniform input: every steady-state
+    4096-sample block within 1e-6 of the double sum of fft/src/main.c:193-204."""
+    nh, nx = 8191, 150000
+    rng = np.random.default_rng(8191)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (1, nx)).astype(np.float32)
+    try:
+        plan = dsp_amd.OlsPlan(h, fft_n)
+    except dsp_amd.DspmiError:
+        pytest.skip("no %d-point overlap-save kernel" % fft_n)
+    y = plan.exec(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = oracle.fir_batch_f32(x, h, nx)
+    worst = check_blocks(y[0], want[0], x[0], h, (nh, plan.fft_length))
+    assert 0 < worst <= TOL_FIR
+
+
+def test_ols_history_and_agreement_with_direct_kernel(monkeypatch):
     rng = np.random.default_rng(4)
     nh, nchan, nx = 2049, 3, 30000
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     x = rng.uniform(-1, 1, (nchan, 2 * nx)).astype(np.float32)
     xd = torch.from_numpy(x).cuda()
-    ols, direct = dsp_amd.OlsPlan(h), dsp_amd.FirPlan(h, "f32")
+    ols = dsp_amd.OlsPlan(h)
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")   # the plan alone would run overlap-save here too
+    direct = dsp_amd.FirPlan(h, "f32")
+    assert "mfma" in direct.variant
     first = ols.exec(xd[:, :nx].contiguous())
     hist = xd[:, nx - (nh - 1):nx].contiguous()
     second = ols.exec(xd[:, nx:].contiguous(), hist=hist)
     whole = direct.exec(xd)
     got = torch.cat([first, second], dim=1)
     err = ((got - whole).double().norm(dim=1) / whole.double().norm(dim=1)).max().item()
-    assert err <= TOL_OLS
+    assert err <= TOL_FIR
     want = oracle.fir_batch_f32(x[:1, :6000], h, 6000)
-    assert rel_l2(got[0, :6000].cpu().numpy(), want[0]) <= TOL_OLS
+    check_blocks(got[0, :6000].cpu().numpy(), want[0], x[0, :6000], h, "history")
 
 
 def test_ols_long_signal_round_properties():
