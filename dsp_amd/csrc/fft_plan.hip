@@ -15,6 +15,7 @@
 #include "common.h"
 #include "fft_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -267,6 +268,41 @@ __global__ __launch_bounds__(256) void s16x2_to_mono_kernel(float *__restrict__ 
 }  // namespace
 
 // ---------------------------------------------------------------------------
+// scratch of the entry point that allocates nothing
+// ---------------------------------------------------------------------------
+
+// dspmi_fft_exec_c2c_noalloc runs the multi-kernel any-length transform with its M-point work
+// frames in this array instead of a buffer from hipMalloc.  Every device the library runs on
+// holds its own copy, at its own address, until the process ends.  In host code the array's
+// name is only a handle for hipGetSymbolAddress: the address kernels are given is the one
+// that call returns for the current device, kept in g_noalloc_ptr.
+constexpr size_t kNoAllocScratchBytes = (size_t)DSPMI_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_noalloc_ptr[kMaxDevices];
+
+// Device address of `scratch` on `device`, which must be the current device.  Resolved once per
+// device (at plan creation, else on the entry point's first call there).
+int noalloc_scratch(int device, void **out)
+{
+    if (device < 0 || device >= kMaxDevices) return dspmi::fail(DSPMI_EINVAL, "noalloc scratch: device %d out of range", device);
+    void *p = g_noalloc_ptr[device].load(std::memory_order_acquire);
+    if (!p) {
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return dspmi::fail(DSPMI_EIO, "noalloc scratch: hipGetSymbolAddress on device %d -> %s", device, hipGetErrorString(e));
+        g_noalloc_ptr[device].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return DSPMI_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------
 
@@ -316,17 +352,31 @@ int run_pow2(const dspmi::FftKernel *k, const void *in, void *out, const void *t
     return (stream_policy ? k->fn_stream : k->fn)(in, out, tw, batch, backward, num_cu, s);
 }
 
+// fixed_work: work frames supplied by the caller (fixed_bytes of them) instead of the plan's
+// own buffer, which an execute may have to grow -- nothing is allocated or freed then.
 template <typename T>
-int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int backward, hipStream_t s)
+int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int backward, hipStream_t s,
+              void *fixed_work = nullptr, size_t fixed_bytes = 0)
 {
     if (pl->kern) return run_pow2(pl->kern, in, out, pl->tw_n, batch, backward, pl->esz, pl->num_cu, s);
     // Bluestein: one kernel where it exists (DSPMI_BLUESTEIN_COMPOSED=1: the five separate ones)
     if (pl->blu && !getenv("DSPMI_BLUESTEIN_COMPOSED"))
         return pl->blu(in, out, pl->chirp, pl->filt, pl->tw_M, pl->n, batch, backward, pl->num_cu, s);
     const unsigned n = pl->n, M = pl->M;
-    int rc = ensure_work(pl, 0, batch * (size_t)M * sizeof(C<T>));
-    if (rc != DSPMI_OK) return rc;
-    C<T> *w = static_cast<C<T> *>(pl->work[0]);
+    int rc = DSPMI_OK;
+    C<T> *w;
+    if (fixed_work) {
+        if (batch > fixed_bytes / ((size_t)M * sizeof(C<T>)))
+            return dspmi::fail(DSPMI_EINVAL,
+                               "fft_exec_c2c_noalloc: %zu frames of n = %u need %zu work frames of %u points, the static "
+                               "scratch of %zu bytes holds %zu",
+                               batch, n, batch, M, fixed_bytes, fixed_bytes / ((size_t)M * sizeof(C<T>)));
+        w = static_cast<C<T> *>(fixed_work);
+    } else {
+        rc = ensure_work(pl, 0, batch * (size_t)M * sizeof(C<T>));
+        if (rc != DSPMI_OK) return rc;
+        w = static_cast<C<T> *>(pl->work[0]);
+    }
     hipLaunchKernelGGL(bluestein_pre_kernel<T>, dim3(ew_grid(batch * M, pl->num_cu)), dim3(256), 0, s,
                        static_cast<const C<T> *>(in), static_cast<const C<T> *>(pl->chirp), w, n, M, batch, backward);
     DSPMI_HIP(hipGetLastError());
@@ -606,6 +656,10 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     int rc = DSPMI_OK;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) rc = dspmi::fail(DSPMI_EIO, "fft_create: hipGetDeviceProperties failed");
     else pl->num_cu = prop.multiProcessorCount;
+    if (rc == DSPMI_OK) {
+        void *unused = nullptr;
+        rc = noalloc_scratch(device, &unused);  // set-up time: the no-allocation entry point then only reads the table
+    }
     if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n, n, precision);
     if (rc == DSPMI_OK && kh) rc = upload_twiddles(&pl->tw_half, n / 2, precision);
     if (rc == DSPMI_OK && kM) rc = precision == DSPMI_F64 ? setup_bluestein<double>(pl) : setup_bluestein<float>(pl);
@@ -649,6 +703,28 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
     const int backward = sign == DSPMI_BACKWARD;
     return plan->precision == DSPMI_F64 ? c2c_typed<double>(plan, in, out, batch, backward, s)
                                         : c2c_typed<float>(plan, in, out, batch, backward, s);
+}
+
+int dspmi_fft_exec_c2c_noalloc(dspmi_fft_t plan, const void *in, void *out, size_t batch, int sign, void *stream)
+{
+    if (!plan) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: null plan");
+    if (int rc = dspmi::check_device(plan->device, "fft_exec_c2c_noalloc")) return rc;
+    if (sign != DSPMI_FORWARD && sign != DSPMI_BACKWARD)
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: sign must be -1 or +1");
+    if (batch == 0) return DSPMI_OK;
+    if (!in || !out) return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: null buffer");
+    if (in != out && ranges_overlap(in, batch * (size_t)plan->n * plan->esz, out, batch * (size_t)plan->n * plan->esz))
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: in and out overlap without being the same buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan->n == 1) {
+        if (in != out) DSPMI_HIP(hipMemcpyAsync(out, in, batch * plan->esz, hipMemcpyDeviceToDevice, s));
+        return DSPMI_OK;
+    }
+    void *work = nullptr;
+    if (int rc = noalloc_scratch(plan->device, &work)) return rc;
+    const int backward = sign == DSPMI_BACKWARD;
+    return plan->precision == DSPMI_F64 ? c2c_typed<double>(plan, in, out, batch, backward, s, work, kNoAllocScratchBytes)
+                                        : c2c_typed<float>(plan, in, out, batch, backward, s, work, kNoAllocScratchBytes);
 }
 
 int dspmi_fft_exec_r2c(dspmi_fft_t plan, const void *in, void *out, size_t batch, void *stream)

@@ -50,6 +50,7 @@ _SIGS = {
     "dspmi_fft_create": (C.c_int, [C.POINTER(_vp), _u, C.c_int, C.c_int]),
     "dspmi_fft_destroy": (C.c_int, [_vp]),
     "dspmi_fft_exec_c2c": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp]),
+    "dspmi_fft_exec_c2c_noalloc": (C.c_int, [_vp, _vp, _vp, _sz, C.c_int, _vp]),
     "dspmi_fft_exec_r2c": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "dspmi_fft_exec_c2r": (C.c_int, [_vp, _vp, _vp, _sz, _vp]),
     "dspmi_fft_exec_filter": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _vp]),
@@ -221,6 +222,16 @@ class FftPlan:
         assert out.is_cuda and out.dtype == ct and out.is_contiguous() and out.shape == x.shape
         batch = x.numel() // self.n
         _check(lib().dspmi_fft_exec_c2c(self._h, x.data_ptr(), out.data_ptr(), batch, sign, _stream()), "fft_exec_c2c")
+        return out
+
+    def c2c_noalloc(self, x, sign=FORWARD, out=None):
+        """c2c through the entry point that allocates no device memory (`out` must be given:
+        allocating it here would defeat the purpose)."""
+        ct, _ = self._types()
+        assert x.is_cuda and x.dtype == ct and x.is_contiguous() and x.shape[-1] == self.n
+        assert out is not None and out.is_cuda and out.dtype == ct and out.is_contiguous() and out.shape == x.shape
+        _check(lib().dspmi_fft_exec_c2c_noalloc(self._h, x.data_ptr(), out.data_ptr(), x.numel() // self.n, sign, _stream()),
+               "fft_exec_c2c_noalloc")
         return out
 
     def r2c(self, x, out=None):

@@ -155,6 +155,20 @@ int dspmi_fft_destroy(dspmi_fft_t plan);
 int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                        int sign, void *stream);
 
+/* dspmi_fft_exec_c2c for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
+ * the reference.  Same arguments and results as dspmi_fft_exec_c2c; the difference is where
+ * the multi-kernel any-length transform (double precision, lengths that are not a power of
+ * two) keeps its work frames: not in the plan's own buffer, which an execute may have to
+ * grow, but in a static device array of DSPMI_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends.  The call performs no hipMalloc / hipFree.
+ * A batch whose work frames (batch * M * 16 bytes, M = the power of two >= 2n-1) exceed the
+ * array is refused with DSPMI_EINVAL.  All calls on one GPU share the array: calls that
+ * overlap in time on one GPU (two streams, two threads) race, whatever plans they use. */
+#define DSPMI_NOALLOC_SCRATCH_BYTES (16u << 20)
+int dspmi_fft_exec_c2c_noalloc(dspmi_fft_t plan, const void *in, void *out, size_t batch,
+                               int sign, void *stream);
+
 /* Real-input forward transform: in [batch][n] reals, out [batch][n/2+1]
  * complex (bins 0..n/2), the fftw_plan_dft_r2c_1d contract
  * (fft/src/main.c:155-158).  Even n with a power-of-two half runs the fused real-input

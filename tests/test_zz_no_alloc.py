@@ -1,0 +1,57 @@
+"""The entry point that allocates nothing (dspmi_fft_exec_c2c_noalloc) against dspmi_fft_exec_c2c,
+through the C ABI: two calls in a row on one GPU, the second with a smaller input, so stale
+contents of the shared static scratch would show."""
+import numpy as np
+import pytest
+import torch
+
+import dsp_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(batch, n, dtype, seed):
+    rng = np.random.default_rng(seed)
+    z = rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))
+    return torch.from_numpy(z.astype(dtype)).cuda()
+
+
+@pytest.mark.parametrize("n,dtype", [(480, "f64"), (482, "f64"), (1000, "f64"), (480, "f32"), (1024, "f64")])
+def test_no_alloc_c2c_matches_the_allocating_entry_point(n, dtype):
+    ct = np.complex128 if dtype == "f64" else np.complex64
+    plan = dsp_amd.FftPlan(n, dtype)
+    for call, (batch, sign) in enumerate([(37, dsp_amd.FORWARD), (5, dsp_amd.BACKWARD)]):
+        z = _frames(batch, n, ct, 100 * n + call)
+        want = plan.c2c(z, sign)
+        got = torch.full_like(z, float("nan"))
+        plan.c2c_noalloc(z, sign, out=got)
+        torch.cuda.synchronize()
+        # the same kernels on the same inputs: bit for bit
+        assert torch.equal(torch.view_as_real(got), torch.view_as_real(want)), (n, dtype, call)
+        # and both against the oracle's DFT
+        ref = oracle.dft(z[0].cpu().numpy().astype(np.complex128), sign)
+        err = np.linalg.norm(got[0].cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert err <= (1e-13 if dtype == "f64" else 1e-5), (n, dtype, call, err)
+
+
+def test_no_alloc_c2c_in_place_and_limits():
+    n = 482
+    plan = dsp_amd.FftPlan(n, "f64")
+    z = _frames(9, n, np.complex128, 7)
+    want = plan.c2c(z)
+    buf = z.clone()
+    plan.c2c_noalloc(buf, out=buf)
+    assert torch.equal(torch.view_as_real(buf), torch.view_as_real(want))
+    # 482 points ride 1024-point work frames of 16 KiB: the 16 MiB array holds 1024 of them
+    L = dsp_amd.lib()
+    big = torch.empty((1025, n), dtype=torch.complex128, device="cuda")
+    rc = L.dspmi_fft_exec_c2c_noalloc(plan._h, big.data_ptr(), big.data_ptr(), 1025, -1, None)
+    assert rc == -22 and b"static" in L.dspmi_last_error()
+    ok = torch.empty((1024, n), dtype=torch.complex128, device="cuda").normal_()
+    assert L.dspmi_fft_exec_c2c_noalloc(plan._h, ok.data_ptr(), ok.data_ptr(), 1024, -1, None) == 0
+    torch.cuda.synchronize()
+    # a smaller call right after the largest one
+    small = z[:2].clone()
+    plan.c2c_noalloc(small, out=small)
+    assert torch.equal(torch.view_as_real(small), torch.view_as_real(want[:2]))
