@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the FIR / FFT hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload fft1024|fir127|fir16]
+    python bench.py --gpus N --steps K --warmup W [--workload fft1024|fir127|fir16|ols8191|fir8191|chain|ols8191_split|c1]
 
 One "step" is one pass of the hot path over one batch of synthetic input that
 is already resident in HBM.  The default workload is BASELINE.json configs[1]:
@@ -16,7 +16,15 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  HIP events recorded on the launch stream around the timed region
   cpu_baseline : the oracle's CPU port timed on a bounded sample of the same
                  workload on this box's host cores (rank 0, N = 1 only)
-  secondary    : short measurements of the two FIR regimes (127 and 16 taps)
+  secondary    : short measurements of the other BASELINE configs, each with its own roofline
+                 block: the two FIR regimes (16 and 127 taps), the 8191-tap signal by
+                 overlap-save and by the direct kernel, and the tonegen -> FIR -> FFT chain
+  pcie_inclusive : the headline workload with host (pinned) buffers in and out, on a bounded sample
+
+--workload ols8191_split is the one workload with a data-path collective: one 2^26-sample signal
+is cut into one output segment per rank, each rank filters its segment (its input slice carries
+the nh-1 samples of halo, so ranks never exchange neighbours' samples) and one all_gather puts
+the output together on every rank ("scaling": "strong").
 """
 import argparse
 import json
@@ -46,9 +54,13 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir127_direct", "fir16", "c1", "fir8191", "ols8191", "chain"])
+    # default: 200 launches of ~3 ms, so the timed region (0.6 s) is long enough for the clocks
+    # to settle inside it and for a sampling monitor to see the GPU busy
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir127_direct", "fir16", "c1", "fir8191", "ols8191",
+                                                             "ols8191_split", "chain"])
+    ap.add_argument("--ols-n", type=int, default=0, help="8191-tap overlap-save: transform length (0 = the plan's choice)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
@@ -187,7 +199,7 @@ def make_long(args, rank, use_ols):
     x = uniform((1, args.long_samples), 0xD5B0 + 4 + rank, "cuda")
     y = torch.empty_like(x)
     if use_ols:
-        plan = dsp_amd.OlsPlan(taps)
+        plan = dsp_amd.OlsPlan(taps, args.ols_n)
         kernel = "ols_fft%d" % plan.fft_length
         fn = lambda: plan.exec(x, y=y)
     else:
@@ -202,7 +214,42 @@ def make_long(args, rank, use_ols):
                 flop_per_unit=2.0 * nh, bytes_per_unit=8.0, bound="hbm" if use_ols else "fp32", samples_per_unit=1,
                 workload="one %d-sample signal, %d taps, %s" % (args.long_samples, nh,
                                                                 "overlap-save" if use_ols else "direct"))
+    if use_ols:
+        n = plan.fft_length
+        info["note"] = ("one kernel, one pass over HBM: 8 B per sample algorithmic; blocks of %d samples overlap by %d, so the "
+                        "kernel itself reads %.2f B and writes 4 B per output" % (n, nh - 1, 4.0 * n / (n - nh + 1)))
     return fn, info, (plan, x, y)
+
+
+def make_long_split(args, rank, world):
+    """BASELINE config 4 over several GPUs: the 2^26-sample signal's outputs are cut into one
+    segment per rank; a rank's input slice already holds the nh-1 samples before its segment, so
+    the only exchange is the all_gather of the outputs (RCCL over xGMI; gloo in rehearsals)."""
+    from dsp_amd import parallel
+    nh, nx = 8191, args.long_samples
+    taps = sinc_taps(nh)
+    lo, hi, in_lo = parallel.segment_plan(nx, nh, world)[rank]
+    # every rank draws the same signal and keeps its own slice (synthetic stand-in for the scatter)
+    g = torch.Generator(device="cuda").manual_seed(0xD5B0 + 4)
+    whole = torch.rand((nx,), device="cuda", generator=g, dtype=torch.float32) * 2 - 1
+    mine = whole[in_lo:hi].clone()
+    del whole
+    torch.cuda.empty_cache()
+    plan = dsp_amd.OlsPlan(taps, args.ols_n)
+    state = {}
+
+    def local_only():
+        state["y"] = parallel.filter_segment(plan, mine, lo, in_lo)
+
+    def step():
+        local_only()
+        state["full"] = parallel.gather_segments(state["y"], nx, world)
+
+    info = dict(kernel="ols_fft%d + all_gather" % plan.fft_length, units=nx / world, unit_name="samples", nh=nh,
+                flop_per_unit=2.0 * nh, bytes_per_unit=8.0, bound="hbm", samples_per_unit=1, local_only=local_only,
+                workload="one %d-sample signal, %d taps, overlap-save, split into %d halo'd segments, outputs all-gathered"
+                         % (nx, nh, world))
+    return step, info, (plan, mine, state)
 
 
 def make_chain(args, rank):
@@ -247,6 +294,8 @@ def make_chain(args, rank):
     info = dict(kernel="tonegen + %s + r2c_spectrum(%s)" % (fir.variant, fft.variant), units=units, unit_name="samples",
                 nh=nh, flop_per_unit=2.0 * nh + 2.5 * math.log2(nfft), bytes_per_unit=4.0 + 2.0, bound="hbm",
                 samples_per_unit=1, fir_fft_ms=fir_fft_ms,
+                note="algorithmic bytes: 4 B per generated sample + 2 B of spectrum per sample (N/2+1 floats per N samples); "
+                     "the stages hand their results on through HBM, which the roof does not allow for",
                 workload="chain: tones -> %d-tap FIR -> N=%d r2c -> |X|/sum, %d channels x %d samples in %d chunks"
                          % (nh, nfft, nchan, chunk * nchunk, nchunk))
     return step, info, (gen, x, fir, fft, y, ps, hist)
@@ -254,29 +303,28 @@ def make_chain(args, rank):
 
 def measured_traffic(info):
     """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes
-    (profiles/r1_traffic.json), or None when the workload was not profiled at this size."""
+    (profiles/traffic.json, filled from separate --pmc FETCH_SIZE / WRITE_SIZE runs), or None
+    when the workload was not profiled at this size."""
     try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        tab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return None
-    key = None
-    if info.get("n") == 1024 and info["units"] == 1 << 20:
-        key = "fft_f32_n1024 x 1048576 frames"
-    elif "nh" in info and info["units"] == 512 << 20 and "mfma" in info["kernel"]:
-        key = "fir_f32_mfma 512 ch x 1048576 samples"
-    elif info.get("nh") == 127 and info["units"] == 512 << 20 and info["kernel"] == "fir_f32_overlap_save_n1024":
-        key = "fir_f32_overlap_save_n1024 512 ch x 1048576 samples, 127 taps"
-    return tab[key]["hbm_bytes"] if key in tab else None
+    key = "%s | %s" % (info["kernel"], info["workload"])
+    ent = tab.get(key)
+    return ent["hbm_bytes"] if ent else None
 
 
 def roofline(info, ms_per_launch):
     sec = ms_per_launch * 1e-3
     if info["bound"] == "hbm":
         achieved = info["bytes_per_unit"] * info["units"] / sec / 1e9
-        return {"bound": "hbm", "kernel": info["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(info),
-                "launch_ms": round(ms_per_launch, 4),
-                "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
+        out = {"bound": "hbm", "kernel": info["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(info),
+               "launch_ms": round(ms_per_launch, 4),
+               "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
+        if "note" in info:
+            out["note"] = info["note"]
+        return out
     achieved = info["flop_per_unit"] * info["units"] / sec / 1e12
     out = {"bound": "mfma", "dtype_peak": "f32 MFMA dense = FP32 vector peak", "kernel": info["kernel"], "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
            "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": measured_traffic(info),
@@ -402,6 +450,65 @@ def cpu_baseline_fir(nh, target_s=8.0):
     return out
 
 
+def cpu_as_shipped(target_s=2.0):
+    """The reference's FIR loops built the way the reference builds them: gcc -Wall, no -O
+    (convolution/do_build.sh:2, fft/src/do_build.sh:5), one thread.  conv0 with the 16-tap table
+    and convolve with 127 taps, restated in the oracle and compiled with those flags."""
+    import ctypes as C
+    import oracle
+    L = oracle.lib("_O0")
+    rng = np.random.default_rng(0)
+    nx = 1 << 16
+    x = rng.uniform(-1, 1, nx)
+    y = np.empty(nx)
+    dp = C.POINTER(C.c_double)
+    out = {}
+    for name, nh, call in (("conv0_16_taps", 16, "oracle_conv0"), ("convolve_127_taps", 127, "oracle_convolve")):
+        h = np.asarray(TAPS16 if nh == 16 else sinc_taps(nh), dtype=np.float64)
+        if call == "oracle_conv0":
+            run = lambda: L.oracle_conv0(x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh, y.ctypes.data_as(dp))
+        else:
+            run = lambda: L.oracle_convolve(y.ctypes.data_as(dp), nx, x.ctypes.data_as(dp), nx, h.ctypes.data_as(dp), nh)
+        t0 = time.perf_counter()
+        run()
+        per = time.perf_counter() - t0
+        reps = int(max(1, min(1024, target_s / per)))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": float("%.4g" % (reps * nx / dt / 1e9)), "unit": "Gsamples/s", "cores": 1, "kind": "port",
+                     "flags": "gcc -Wall (no -O), as the reference's build scripts",
+                     "sample": "%d blocks of %d samples" % (reps, nx)}
+    return out
+
+
+def pcie_inclusive_fft(frames=1 << 16, n=1024, reps=5):
+    """The headline transform with HOST buffers on both sides, as the drop-in boundary hands them
+    over: pinned host -> device, transform, device -> pinned host, one stream, no overlap."""
+    plan = dsp_amd.FftPlan(n, "f32")
+    hin = torch.empty((frames, n, 2), dtype=torch.float32).uniform_(-1, 1).pin_memory()
+    hout = torch.empty((frames, n, 2), dtype=torch.float32).pin_memory()
+    din = torch.empty((frames, n, 2), dtype=torch.float32, device="cuda")
+    dout = torch.empty_like(din)
+
+    def once():
+        din.copy_(hin, non_blocking=True)
+        plan.c2c(torch.view_as_complex(din), dsp_amd.FORWARD, out=torch.view_as_complex(dout))
+        hout.copy_(dout, non_blocking=True)
+        torch.cuda.synchronize()
+
+    once()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    dt = (time.perf_counter() - t0) / reps
+    return {"gflops": round(5.0 * n * math.log2(n) * frames / dt / 1e9, 1),
+            "host_gbytes_per_s_each_way": round(frames * n * 8 / dt / 1e9, 1),
+            "ms": round(dt * 1e3, 3),
+            "sample": "%d frames of N=%d: pinned host -> device, transform, device -> pinned host, serialised" % (frames, n)}
+
+
 # ---------------------------------------------------------------------------
 
 def main():
@@ -416,6 +523,9 @@ def main():
     elif args.workload in ("fir8191", "ols8191"):
         fn, info, keep = make_long(args, rank, args.workload == "ols8191")
         args.no_secondary = True
+    elif args.workload == "ols8191_split":
+        fn, info, keep = make_long_split(args, rank, world)
+        args.no_secondary = True
     elif args.workload == "c1":
         # BASELINE config 1: the 16-tap table over one 1M-sample signal (the reference's CPU-runnable case)
         args.channels, args.samples, args.no_secondary = 1, 1 << 20, True
@@ -423,7 +533,12 @@ def main():
     else:
         fn, info, keep = make_fir(args, rank, 16 if args.workload == "fir16" else 127, direct=args.workload == "fir127_direct")
 
+    if args.workload != "fft1024" and args.steps > 50:
+        args.steps = 50      # the default step count is sized for the 3 ms headline launch
     dt, ms_launch = timed(fn, args.steps, args.warmup, world)
+    local_ms = None
+    if "local_only" in info:
+        _, local_ms = timed(info.pop("local_only"), args.steps, 1, world)
     units_total = info["units"] * world * args.steps
     gflops = info["flop_per_unit"] * units_total / dt / 1e9
     gsamples = info["samples_per_unit"] * units_total / dt / 1e9
@@ -432,22 +547,42 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         del keep, fn
         torch.cuda.empty_cache()
-        for nh, direct in ((16, False), (127, False), (127, True)):
-            if args.workload == ("fir%d%s" % (nh, "_direct" if direct else "")):
-                continue
-            f2, i2, k2 = make_fir(args, rank, nh, direct)
-            nsec = 10
-            d2, ms2 = timed(f2, nsec, 3, 1)
-            secondary.append({"workload": i2["workload"],
-                              "gsamples_per_s": round(i2["units"] * nsec / d2 / 1e9, 2),
-                              "gflops": round(i2["flop_per_unit"] * i2["units"] * nsec / d2 / 1e9, 1),
-                              "roofline": roofline(i2, ms2)})
+        jobs = [("fir", 16, False), ("fir", 127, False), ("fir", 127, True), ("ols8191",), ("fir8191",), ("chain",)]
+        for job in jobs:
+            if job[0] == "fir":
+                _, nh, direct = job
+                if args.workload == ("fir%d%s" % (nh, "_direct" if direct else "")):
+                    continue
+                f2, i2, k2 = make_fir(args, rank, nh, direct)
+                nsec = 10
+            elif job[0] == "chain":
+                f2, i2, k2 = make_chain(args, rank)
+                nsec = 5
+            else:
+                f2, i2, k2 = make_long(args, rank, job[0] == "ols8191")
+                nsec = 20 if job[0] == "ols8191" else 3
+            d2, ms2 = timed(f2, nsec, 2, 1)
+            ent = {"workload": i2["workload"],
+                   "gsamples_per_s": round(i2["units"] * nsec / d2 / 1e9, 2),
+                   "gflops": round(i2["flop_per_unit"] * i2["units"] * nsec / d2 / 1e9, 1),
+                   "ms_per_step": round(d2 / nsec * 1e3, 4),
+                   "roofline": roofline(i2, ms2)}
+            if "fir_fft_ms" in i2:
+                ent["fir_fft_stages_only_ms"] = round(i2["fir_fft_ms"], 3)
+            secondary.append(ent)
             del f2, k2
             torch.cuda.empty_cache()
 
     cpu = None
+    extra = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_fft() if args.workload == "fft1024" else cpu_baseline_fir(info["nh"])
+        try:
+            extra["cpu_fir_as_shipped"] = cpu_as_shipped()
+        except (OSError, AttributeError) as e:
+            print("cpu_as_shipped skipped (%s)" % e, file=sys.stderr)
+        if args.workload == "fft1024":
+            extra["pcie_inclusive"] = pcie_inclusive_fft()
 
     if rank == 0:
         is_fft = args.workload == "fft1024"
@@ -463,15 +598,21 @@ def main():
             "unit": "GFLOP/s" if is_fft else "Gsamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.workload == "ols8191_split" else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": info["workload"], "kernel": info["kernel"], "per_gpu_units": info["units"],
-                       "unit_name": info["unit_name"], "sharding": "frames/channels split across ranks, no collective"},
+                       "unit_name": info["unit_name"],
+                       "sharding": ("one signal cut into halo'd output segments, one all_gather of the outputs"
+                                    if args.workload == "ols8191_split" else "frames/channels split across ranks, no collective")},
             "gsamples_per_s": round(gsamples, 2), "gflops": round(gflops, 1),
             "roofline": roofline(info, ms_launch),
             "cpu_baseline": cpu,
             "secondary": secondary,
         }
+        line.update(extra)
+        if local_ms is not None:
+            line["without_gather"] = {"ms_per_step": round(local_ms, 4),
+                                      "gsamples_per_s": round(info["units"] * world / local_ms / 1e6, 2)}
         if args.workload == "c1":
             # the same signal through the drop-in host routine: double precision, host buffers in
             # and out over PCIe, plan and device buffers created per call as the reference does

@@ -42,6 +42,16 @@ def split_history(x_with_halo, out_lo, in_lo, nh):
     return hist, body
 
 
+def filter_segment(plan, x_with_halo, out_lo, in_lo):
+    """One rank's share of a long signal through a FIR / overlap-save plan on its GPU.
+
+    x_with_halo: 1-D CUDA tensor x[in_lo:out_hi] (the rank's outputs' inputs plus the nh-1 samples
+    before them, as segment_plan lays them out); plan: FirPlan or OlsPlan with .nh and
+    .exec(x[nchan, nx], hist=).  Returns y[out_lo:out_hi]."""
+    hist, body = split_history(x_with_halo, out_lo, in_lo, plan.nh)
+    return plan.exec(body[None, :].contiguous(), hist=hist[None, :].contiguous())[0]
+
+
 def gather_segments(y_local, nx, world=None, group=None):
     """all_gather of the per-rank output segments into the full-length signal on every rank.
 
@@ -54,10 +64,15 @@ def gather_segments(y_local, nx, world=None, group=None):
     longest = -(-nx // world)
     pad = torch.zeros(y_local.shape[:-1] + (longest,), dtype=y_local.dtype, device=y_local.device)
     pad[..., :y_local.shape[-1]] = y_local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    # gloo (CPU rehearsals of the multi-rank path, ranks sharing one GPU) has no all_gather of
+    # device tensors: stage through the host there; RCCL gathers device to device over xGMI
+    staged = pad.is_cuda and dist.get_backend(group) == "gloo"
+    send = pad.cpu() if staged else pad
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
     out = []
     for r, p in enumerate(parts):
         lo, hi = shard_range(nx, world, r)
         out.append(p[..., :hi - lo])
-    return torch.cat(out, dim=-1)
+    full = torch.cat(out, dim=-1)
+    return full.to(y_local.device) if staged else full
