@@ -203,18 +203,11 @@ __device__ __forceinline__ void load_twiddles(C<T> *twr, const C<T> *__restrict_
 // lane (twr), 2 = a per-workgroup LDS table laid out [r-1][j mod NS] (twr points at it),
 // 3 = that table for passes with NS <= 16 and, for the others, two short LDS tables
 // A[a] = W^(64a), B[b] = W^b whose product is the twiddle (twr points at A, B follows).
-template <typename T, int N, int NT, int R, int NS, bool FIRST, bool LAST, int TW>
-__device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
+// Twiddles and butterflies of one pass over the P register-resident points of this lane.
+template <typename T, int N, int NT, int R, int NS, int TW>
+__device__ __forceinline__ void pass_butterflies(C<T> *v, const C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
 {
     constexpr int P = N / NT, NB = P / R;
-    if constexpr (R == 1) return;
-    if constexpr (!FIRST) {
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < R; r++) v[b * R + r] = lds[pad(tl + NT * b + r * (N / R))];
-        frame_sync<NT>();
-    }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         if constexpr (NS > 1) {
@@ -234,6 +227,21 @@ __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, co
         }
         dft_reg<R, 1>(&v[b * R]);
     }
+}
+
+template <typename T, int N, int NT, int R, int NS, bool FIRST, bool LAST, int TW>
+__device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, const C<T> *__restrict__ tw, unsigned tl)
+{
+    constexpr int P = N / NT, NB = P / R;
+    if constexpr (R == 1) return;
+    if constexpr (!FIRST) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < R; r++) v[b * R + r] = lds[pad(tl + NT * b + r * (N / R))];
+        frame_sync<NT>();
+    }
+    pass_butterflies<T, N, NT, R, NS, TW>(v, twr, tw, tl);
     if constexpr (!LAST) {
 #pragma unroll
         for (int b = 0; b < NB; b++) {
@@ -272,12 +280,13 @@ __device__ __forceinline__ void setup_lds_twiddles(char *smem_raw, const C<T> *_
 // frame itself.  Only the first twiddled pass (NS = R0 <= 16) keeps its table; the other passes
 // build W^e from A[e >> 6] * B[e & 63], N/64 + 64 entries in all, at the price of one complex
 // multiplication per twiddle.  Ends with a barrier.
-template <typename T, int N, int BT, int FPB, int R0, int R1>
+template <typename T, int N, int BT, int FPB, int R0, int R1, size_t IMAGE_BYTES = (size_t)FPB * padded_len(N) * sizeof(C<T>)>
 __device__ __forceinline__ void setup_lds_twiddles_split(char *smem_raw, const C<T> *__restrict__ tw, const C<T> *&tw1,
                                                          const C<T> *&tw2, const C<T> *&tw3)
 {
     static_assert(R0 <= 16 && N % 64 == 0, "first pass table only for NS <= 16");
-    C<T> *t1 = reinterpret_cast<C<T> *>(smem_raw) + (size_t)FPB * padded_len(N);
+    static_assert(IMAGE_BYTES % sizeof(C<T>) == 0, "tables start on a complex element");
+    C<T> *t1 = reinterpret_cast<C<T> *>(smem_raw + IMAGE_BYTES);
     C<T> *ta = t1 + (R1 > 1 ? (R1 - 1) * R0 : 0);
     if constexpr (R1 > 1)
         for (unsigned i = threadIdx.x; i < (R1 - 1) * R0; i += BT) t1[i] = tw[(i % R0) * (i / R0 + 1) * (N / (R0 * R1))];
@@ -910,6 +919,222 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
     }
 }
 
+// ---------------------------------------------------------------------------
+// overlap-save, long blocks: a radix-K1 stage across the workgroup, then one 1024-point
+// transform per wave
+// ---------------------------------------------------------------------------
+
+// N = K1 * 1024 points per block pair (K1 = 32: 32768).  With n = n2 + 1024 n1 and
+// k = k1 + K1 k2 the transform factors as
+//   X[k1 + K1 k2] = sum_n2 W_1024^(n2 k2) . W_N^(n2 k1) . sum_n1 x[n2 + 1024 n1] W_K1^(n1 k1):
+// lane n2 of a 1024-lane workgroup holds x[n2 + 1024 n1] for every n1 (coalesced loads) and does
+// the radix-K1 sum and the W_N^(n2 k1) factors in registers; one exchange across the workgroup
+// then hands wave w the K1/16 rows k1 it owns, and each row's 1024-point transform runs inside
+// the wave (passes exchanged through the wave's own LDS region, no workgroup barrier).  The
+// spectrum is multiplied by H there, and the second transform is the mirror image (the same
+// factorisation read the other way: rows first, then W_N^(k1 n2) and the radix-K1 sum), so it
+// ends with lane n2 holding y[n2 + 1024 n1] -- the layout it was loaded in.
+// A block costs two workgroup-wide exchanges instead of six, and between them the sixteen waves
+// run independently, so one wave's LDS traffic overlaps another's butterflies.  The frame
+// (256 KB as complex points) exceeds the LDS: the workgroup-wide exchanges move the real parts,
+// then the imaginary parts, through one N-float image; the waves' regions alias it.
+// v[k1] *= tp[1024 k1], eight at a time: the scheduler must not gather all the loads at the top
+// (their values would sit in registers next to the whole frame)
+template <int K1>
+__device__ __forceinline__ void stage_factors(C<float> *v, const C<float> *tp)
+{
+#pragma unroll
+    for (int g = 0; g < K1; g += 8) {
+        C<float> w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = tp[1024 * (g + i)];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (g + i) v[g + i] = cmul(v[g + i], w[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int K1>
+__global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C<float> *__restrict__ tw_sub,
+                                                        const C<float> *__restrict__ tw_stage)
+{
+    typedef float T;
+    constexpr int NS = 1024, NW = 16, SPW = K1 / NW;  // points per row, waves, rows per wave
+    constexpr int R0 = 16, R1 = 4, R2 = 16;           // the row transform: symmetric radix list
+    static_assert(K1 % NW == 0 && K1 <= 32, "rows are dealt out evenly; radix up to 32");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned tl = threadIdx.x, lane = tl & 63, wave = tl >> 6;
+    float *img = reinterpret_cast<float *>(smem_raw);  // [K1][1024], one component at a time
+    C<T> *wreg = reinterpret_cast<C<T> *>(smem_raw) + (size_t)wave * padded_len(NS);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    setup_lds_twiddles<T, NS, 1024, NW, R0, R1, R2, 1>(smem_raw, tw_sub, tw1, tw2, tw3);
+
+    const long nx = a.nx, nh = a.nh, L = a.L;
+    const size_t total = (size_t)a.nchan * a.npair;
+    for (size_t frame = blockIdx.x; frame < total; frame += gridDim.x) {
+        const size_t c = frame / a.npair;
+        const unsigned p = (unsigned)(frame - c * a.npair);
+        const float *xrow = a.x + c * a.x_stride;
+        const float *hrow = a.hist ? a.hist + c * a.hist_stride : nullptr;
+        const long base = (long)(2 * p) * L - (nh - 1);  // sample index of element 0 of the even block
+        const bool second = 2 * p + 1 < a.nblk;
+        const bool interior = base >= 0 && base + L + K1 * NS <= nx && second;  // the same for the whole workgroup
+        // laundered lane index: the stage factors and H are the same for every frame; hoisted out
+        // of the frame loop they would occupy registers through both transforms
+        unsigned tt = tl;
+        asm volatile("" : "+v"(tt));
+
+        // element tl + 1024 n1 of the pair: re = x[base + ...], im = x[base + L + ...]
+        C<T> v[K1];
+        if (interior) {
+            const float *p0 = xrow + base + tt;
+            const float *p1 = p0 + L;
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                v[n1].re = __builtin_nontemporal_load(p0 + NS * n1);
+                v[n1].im = __builtin_nontemporal_load(p1 + NS * n1);
+            }
+        } else {
+            auto sample = [&](long s) -> float {
+                if (s >= 0) return s < nx ? xrow[s] : 0.f;
+                return (hrow && s >= 1 - nh) ? hrow[nh - 1 + s] : 0.f;
+            };
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                const long s = base + tt + NS * n1;
+                v[n1].re = sample(s);
+                v[n1].im = second ? sample(s + L) : 0.f;
+            }
+        }
+
+        // ---- first transform: radix-K1 sum, stage factors, rows ----
+        __builtin_amdgcn_sched_barrier(0);
+        dft_reg<K1, 1>(v);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_factors<K1>(v, tw_stage + tt);
+        C<T> u[SPW][16];
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+#pragma unroll
+            for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = comp ? v[k1].im : v[k1].re;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SPW; s++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float q = img[NS * (wave * SPW + s) + lane + 64 * r];
+                    if (comp) u[s][r].im = q;
+                    else u[s][r].re = q;
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < SPW; s++) {
+            // laundered lane index, once per use: every LDS and table address below is the same
+            // for every row and frame, and would otherwise be computed once and kept (spilled)
+            unsigned la = lane, lh = lane, lb = lane;
+            asm volatile("" : "+v"(la));
+            run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, la);
+            // spectrum times H (stored row by row: H[k1 + K1 k2] at [k1][k2]), conjugated for the
+            // second transform (conj . forward . conj)
+            asm volatile("" : "+v"(lh));
+            const C<T> *hp = a.H + (size_t)NS * (wave * SPW + s) + lh;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const C<T> m = cmul(u[s][r], hp[64 * r]);
+                u[s][r] = {m.re, -m.im};
+            }
+            // ---- second transform: rows, stage factors, radix-K1 sum ----
+            asm volatile("" : "+v"(lb));
+            run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, lb);
+        }
+        __syncthreads();  // the waves' regions alias the image: every wave is done with its rows
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+#pragma unroll
+            for (int s = 0; s < SPW; s++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) img[NS * (wave * SPW + s) + lane + 64 * r] = comp ? u[s][r].im : u[s][r].re;
+            __syncthreads();
+#pragma unroll
+            for (int k1 = 0; k1 < K1; k1++) {
+                const float q = img[NS * k1 + tl];
+                if (comp) v[k1].im = q;
+                else v[k1].re = q;
+            }
+            __syncthreads();
+        }
+        {
+            unsigned t2 = tl;
+            asm volatile("" : "+v"(t2));
+            stage_factors<K1>(v, tw_stage + t2);
+        }
+        dft_reg<K1, 1>(v);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // outputs j = m - (nh-1) >= 0 of each block of the pair; the result is conjugated:
+        // re belongs to the even block, -im to the odd one
+        unsigned to = tl;
+        asm volatile("" : "+v"(to));  // keeps the store predicates from being formed (and kept) early
+        if (interior) {
+            float *q0 = a.y + c * a.y_stride + ((long)(2 * p) * L - (nh - 1)) + to;
+            float *q1 = q0 + L;
+            const int skip = (int)nh - 1 - (int)to;  // element offsets below this are overlap
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                if (NS * n1 >= skip) {
+                    __builtin_nontemporal_store(v[n1].re, q0 + NS * n1);
+                    __builtin_nontemporal_store(-v[n1].im, q1 + NS * n1);
+                }
+            }
+        } else {
+            float *yrow = a.y + c * a.y_stride;
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                const long j = (long)to + NS * n1 - (nh - 1);
+                const long o0 = (long)(2 * p) * L + j;
+                if (j >= 0 && o0 < nx) yrow[o0] = v[n1].re;
+                if (j >= 0 && second && o0 + L < nx) yrow[o0 + L] = -v[n1].im;
+            }
+        }
+    }
+}
+
+template <int K1>
+int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, hipStream_t s)
+{
+    constexpr int NS = 1024, N = K1 * NS;
+    constexpr size_t img = (size_t)N * sizeof(float), regions = (size_t)16 * padded_len(NS) * sizeof(C<float>);
+    constexpr size_t lds = (img > regions ? img : regions) + lds_twiddle_entries(2, 16, 4, 16, 1) * sizeof(C<float>);
+    static_assert(img <= regions, "the row twiddle tables sit behind the waves' regions");
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");
+    auto kern = ols_wave_kernel<K1>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    OlsArgs a;
+    a.x = o.x; a.hist = o.hist; a.y = o.y; a.H = static_cast<const C<float> *>(o.H);
+    a.x_stride = o.x_stride; a.y_stride = o.y_stride; a.hist_stride = o.hist_stride;
+    a.nx = o.nx; a.nh = o.nh; a.L = N - (o.nh - 1);
+    a.nblk = (unsigned)(((unsigned long long)o.nx + a.L - 1) / a.L);
+    a.npair = (a.nblk + 1) / 2;
+    a.nchan = o.nchan;
+    const size_t total = (size_t)a.nchan * a.npair;
+    if (total == 0) return DSPMI_OK;
+    // one workgroup per block pair: the dispatcher hands the next one to whichever CU is free
+    (void)num_cu;
+    const size_t grid = total > 0x7fffffffu ? 0x7fffffffu : total;
+    // tables: exp(-2 pi i k / 1024), k < 1024, then the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]
+    const C<float> *tw_sub = static_cast<const C<float> *>(tables);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, a, tw_sub, tw_sub + NS);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
 template <int N, int NT, int R0, int R1, int R2, int R3, int TW>
 int launch_ols(const dspmi::OlsLaunch &o, const void *tw, int num_cu, hipStream_t s)
 {
@@ -952,6 +1177,7 @@ const OlsEntry kOls[] = {
     OLS(128, 8, 4, 8, 4, 1, 2),        OLS(256, 16, 16, 16, 1, 1, 2),      OLS(512, 32, 16, 2, 16, 1, 2),
     OLS(1024, 64, 16, 4, 16, 1, 2),    OLS(2048, 128, 16, 8, 16, 1, 2),    OLS(4096, 256, 16, 16, 16, 1, 3),
     OLS(8192, 512, 16, 16, 2, 16, 3),  OLS(16384, 1024, 16, 16, 4, 16, 3),
+    {32768, launch_ols_wave<32>},
 };
 
 // ---------------------------------------------------------------------------

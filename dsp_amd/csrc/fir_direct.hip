@@ -633,10 +633,12 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         if constexpr (sizeof(T) == 4) {
             if (!pinned && nh >= kOlsMinTaps && nh <= 8192) {
                 // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
-                // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384
+                // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384; beyond 2048
+                // taps the plan's own default (32768-point blocks)
                 unsigned n = 1024;
                 while (n < 4 * nh && n < 16384) n <<= 1;
-                if (dspmi_ols_create_f32(&pl->ols, taps, nh, n, device) == DSPMI_OK) pl->ols_n = n;
+                if (nh > 2048) n = 0;
+                if (dspmi_ols_create_f32(&pl->ols, taps, nh, n, device) == DSPMI_OK) pl->ols_n = dspmi_ols_fft_length(pl->ols);
                 else pl->ols = nullptr;
             }
         }

@@ -17,6 +17,8 @@
 #include "common.h"
 #include "fft_internal.h"
 
+#include <cmath>
+#include <complex>
 #include <vector>
 
 namespace {
@@ -85,6 +87,40 @@ __global__ __launch_bounds__(256) void ols_scatter_kernel(float *__restrict__ y,
     }
 }
 
+// In-place radix-2 transform on the host, in double (forward, unnormalised; n a power of two):
+// the taps' spectrum is computed once per plan, here, and rounded to f32 once.
+void host_fft(std::vector<std::complex<double>> &z)
+{
+    const size_t n = z.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(z[i], z[j]);
+    }
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (size_t len = 2; len <= n; len <<= 1) {
+        std::vector<std::complex<double>> w(len / 2);
+        for (size_t k = 0; k < len / 2; k++) {
+            const long double a = -two_pi * (long double)k / (long double)len;
+            w[k] = {(double)cosl(a), (double)sinl(a)};
+        }
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; k++) {
+                const std::complex<double> u = z[i + k], t = z[i + k + len / 2] * w[k];
+                z[i + k] = u + t;
+                z[i + k + len / 2] = u - t;
+            }
+    }
+}
+
+// DSPMI_OLS_COMPOSED=1 (A/B knob, read at plan creation): the five-kernel composition
+bool composed_now()
+{
+    const char *env = getenv("DSPMI_OLS_COMPOSED");
+    return env && atoi(env);
+}
+
 inline unsigned ew_grid(size_t total, int num_cu)
 {
     size_t g = (total + 255) / 256;
@@ -112,13 +148,15 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     if (!plan || !taps || nh == 0) return dspmi::fail(DSPMI_EINVAL, "ols_create: null argument or nh == 0");
     unsigned N = fft_n;
     if (N == 0) {
-        // default: the largest single-kernel transform that still keeps >= 3/4 of each block,
-        // else the largest available
+        // default: the smallest transform that keeps >= 3/4 of each block; beyond 2048 taps the
+        // 32768-point kernel (it costs the same per point as the 16384-point one and keeps more)
         N = 16;
         while (N < 4 * nh && N < 16384) N <<= 1;
+        if (nh > 2048 && !composed_now()) N = 32768;
     }
-    if ((N & (N - 1)) || N < 2 * nh || !dspmi::fft_find(N, DSPMI_F32))
-        return dspmi::fail(DSPMI_ENOSYS, "ols_create: transform length %u unusable for %u taps (power of two >= 2*nh, <= 16384)",
+    const bool composed = composed_now();
+    if ((N & (N - 1)) || N < 2 * nh || !(dspmi::fft_find(N, DSPMI_F32) || (!composed && dspmi::ols_find(N))))
+        return dspmi::fail(DSPMI_ENOSYS, "ols_create: transform length %u unusable for %u taps (power of two >= 2*nh, <= 32768)",
                            N, nh);
     if (device < 0) DSPMI_HIP(hipGetDevice(&device));
     int prev = 0;
@@ -129,29 +167,50 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     pl->nh = nh;
     pl->N = N;
     pl->L = N - (nh - 1);
-    pl->kern = dspmi::fft_find(N, DSPMI_F32);
-    {
-        const char *env = getenv("DSPMI_OLS_COMPOSED");  // A/B knob: force the five-kernel composition
-        if (!(env && atoi(env))) pl->fused = dspmi::ols_find(N);
-    }
+    pl->kern = dspmi::fft_find(N, DSPMI_F32);  // the composed path's transform; none beyond 16384 points
+    if (!composed) pl->fused = dspmi::ols_find(N);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) pl->num_cu = prop.multiProcessorCount;
 
-    std::vector<C32> tw(N), h(N, C32{0.f, 0.f});
+    // Blocks beyond 16384 points run the kernel that splits a block into N/1024 rows of 1024
+    // points (fft_stockham.hip, ols_wave_kernel).  Its tables: exp(-2 pi i k / 1024), k < 1024,
+    // followed by the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]; H is stored row by row,
+    // H[k1 + rows * k2] at [k1][k2].
+    const unsigned rows = N > 16384 ? N / 1024 : 0;
     const long double two_pi = 6.283185307179586476925286766559005768L;
-    for (unsigned k = 0; k < N; k++) {
-        const long double a = -two_pi * (long double)k / (long double)N;
-        tw[k] = {(float)cosl(a), (float)sinl(a)};
+    std::vector<C32> tw(rows ? 1024 + (size_t)N : N), h(N, C32{0.f, 0.f});
+    if (rows) {
+        for (unsigned k = 0; k < 1024; k++) {
+            const long double a = -two_pi * (long double)k / 1024.0L;
+            tw[k] = {(float)cosl(a), (float)sinl(a)};
+        }
+        for (unsigned k1 = 0; k1 < rows; k1++)
+            for (unsigned n2 = 0; n2 < 1024; n2++) {
+                const long double a = -two_pi * (long double)(((unsigned long long)k1 * n2) % N) / (long double)N;
+                tw[1024 + (size_t)k1 * 1024 + n2] = {(float)cosl(a), (float)sinl(a)};
+            }
+    } else {
+        for (unsigned k = 0; k < N; k++) {
+            const long double a = -two_pi * (long double)k / (long double)N;
+            tw[k] = {(float)cosl(a), (float)sinl(a)};
+        }
     }
-    for (unsigned j = 0; j < nh; j++) h[j].re = taps[j] / (float)N;  // N is a power of two: exact scaling
-    hipError_t e = hipMalloc(&pl->tw, N * sizeof(C32));
+    {
+        // H = FFT_N(taps) / N
+        std::vector<std::complex<double>> hz(N, {0.0, 0.0});
+        for (unsigned j = 0; j < nh; j++) hz[j] = {(double)taps[j], 0.0};
+        host_fft(hz);
+        for (unsigned k = 0; k < N; k++) {
+            const size_t at = rows ? (size_t)(k % rows) * 1024 + k / rows : k;
+            h[at] = {(float)(hz[k].real() / N), (float)(hz[k].imag() / N)};
+        }
+    }
+    hipError_t e = hipMalloc(&pl->tw, tw.size() * sizeof(C32));
     if (e == hipSuccess) e = hipMalloc(&pl->H, N * sizeof(C32));
-    if (e == hipSuccess) e = hipMemcpy(pl->tw, tw.data(), N * sizeof(C32), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->tw, tw.data(), tw.size() * sizeof(C32), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(pl->H, h.data(), N * sizeof(C32), hipMemcpyHostToDevice);
     int rc = DSPMI_OK;
     if (e != hipSuccess) rc = dspmi::fail(DSPMI_EIO, "ols_create: %s", hipGetErrorString(e));
-    if (rc == DSPMI_OK) rc = pl->kern->fn(pl->H, pl->H, pl->tw, 1, 0, pl->num_cu, nullptr);
-    if (rc == DSPMI_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = dspmi::fail(DSPMI_EIO, "ols_create: sync failed");
     (void)hipSetDevice(prev);
     if (rc != DSPMI_OK) {
         dspmi_ols_destroy(pl);

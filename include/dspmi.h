@@ -205,7 +205,7 @@ const char *dspmi_fft_variant(dspmi_fft_t plan);
  * doc/notes:81-82) applied to overlapping blocks.  A plan holds H = FFT(taps)/N. */
 typedef struct dspmi_ols_plan *dspmi_ols_t;
 
-/* fft_n: transform length (power of two >= 2*nh, <= 16384), or 0 to choose. */
+/* fft_n: transform length (power of two >= 2*nh, <= 32768), or 0 to choose. */
 int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsigned fft_n, int device);
 int dspmi_ols_destroy(dspmi_ols_t plan);
 unsigned dspmi_ols_fft_length(dspmi_ols_t plan);
