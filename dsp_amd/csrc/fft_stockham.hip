@@ -938,22 +938,30 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
 // run independently, so one wave's LDS traffic overlaps another's butterflies.  The frame
 // (256 KB as complex points) exceeds the LDS: the workgroup-wide exchanges move the real parts,
 // then the imaginary parts, through one N-float image; the waves' regions alias it.
-// v[k1] *= tp[1024 k1], eight at a time: the scheduler must not gather all the loads at the top
-// (their values would sit in registers next to the whole frame)
+// The stage factors W^(k1 n2), k1 = 1 .. K1-1, of one lane.  Only the rows k1 = 1, 2, 3 and
+// 4, 8, .. are loaded (ten values instead of thirty-one, so they can be requested at the top of
+// the frame and sit in registers until the radix-K1 sum is done); the others are applied as
+// two factors, W^(4a n2) and W^(b n2): one more rounding on those points (the block error stays
+// at 2.1e-7).
 template <int K1>
-__device__ __forceinline__ void stage_factors(C<float> *v, const C<float> *tp)
-{
+struct StageFactors {
+    C<float> lo[3], hi[K1 / 4 - 1];
+    __device__ __forceinline__ void load(const C<float> *tp)
+    {
 #pragma unroll
-    for (int g = 0; g < K1; g += 8) {
-        C<float> w[8];
+        for (int b = 1; b < 4; b++) lo[b - 1] = tp[1024 * b];
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[i] = tp[1024 * (g + i)];
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-            if (g + i) v[g + i] = cmul(v[g + i], w[i]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int a = 1; a < K1 / 4; a++) hi[a - 1] = tp[1024 * 4 * a];
     }
-}
+    __device__ __forceinline__ void apply(C<float> *v) const
+    {
+#pragma unroll
+        for (int k1 = 1; k1 < K1; k1++) {
+            if (k1 / 4) v[k1] = cmul(v[k1], hi[k1 / 4 - 1]);
+            if (k1 % 4) v[k1] = cmul(v[k1], lo[k1 % 4 - 1]);
+        }
+    }
+};
 
 template <int K1>
 __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C<float> *__restrict__ tw_sub,
@@ -1010,10 +1018,10 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
         }
 
         // ---- first transform: radix-K1 sum, stage factors, rows ----
-        __builtin_amdgcn_sched_barrier(0);
+        StageFactors<K1> sf;
+        sf.load(tw_stage + tt);
         dft_reg<K1, 1>(v);
-        __builtin_amdgcn_sched_barrier(0);
-        stage_factors<K1>(v, tw_stage + tt);
+        sf.apply(v);
         C<T> u[SPW][16];
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
@@ -1038,7 +1046,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             asm volatile("" : "+v"(la));
             run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, la);
             // spectrum times H (stored row by row: H[k1 + K1 k2] at [k1][k2]), conjugated for the
-            // second transform (conj . forward . conj)
+            // second transform (conj . forward . conj).  Requesting H before the transform would
+            // hide its latency but does not fit the 128 registers next to the other row.
             asm volatile("" : "+v"(lh));
             const C<T> *hp = a.H + (size_t)NS * (wave * SPW + s) + lh;
 #pragma unroll
@@ -1049,6 +1058,11 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             // ---- second transform: rows, stage factors, radix-K1 sum ----
             asm volatile("" : "+v"(lb));
             run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, lb);
+        }
+        {
+            unsigned t2 = tl;
+            asm volatile("" : "+v"(t2));
+            sf.load(tw_stage + t2);  // on their way during the exchange
         }
         __syncthreads();  // the waves' regions alias the image: every wave is done with its rows
 #pragma unroll
@@ -1066,13 +1080,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             }
             __syncthreads();
         }
-        {
-            unsigned t2 = tl;
-            asm volatile("" : "+v"(t2));
-            stage_factors<K1>(v, tw_stage + t2);
-        }
+        sf.apply(v);
         dft_reg<K1, 1>(v);
-        __builtin_amdgcn_sched_barrier(0);
 
         // outputs j = m - (nh-1) >= 0 of each block of the pair; the result is conjugated:
         // re belongs to the even block, -im to the odd one
