@@ -84,12 +84,16 @@ struct PerDeviceOnce {
         }                                                                                    \
     } while (0)
 
+// A size or argument the library refuses ends the program with status 255, the status the
+// reference's tools return on their own errors (util/fft/fft.c, util/filter/filter.c: return -1
+// from main); a device failure aborts.
 #define DSPMI_OR_DIE(call)                                                                   \
     do {                                                                                     \
         int r__ = (call);                                                                    \
         if (r__ != DSPMI_OK) {                                                               \
             fprintf(stderr, "libdspmi: %s:%d: %s failed (%d): %s\n", __FILE__, __LINE__,     \
                     #call, r__, dspmi_last_error());                                         \
-            abort();                                                                         \
+            if (r__ == DSPMI_EIO) abort();                                                   \
+            exit(255);                                                                       \
         }                                                                                    \
     } while (0)

@@ -2,7 +2,9 @@
 // reference uses them (fftc/main.c:33-42, fft/src/main.c:156-166,
 // util/filter/filter.c:86-103), over the batched kernels of fft_stockham.hip.
 //
-//  * power-of-two lengths run the Stockham kernels directly;
+//  * power-of-two lengths run the Stockham kernels directly, up to the longest single-workgroup
+//    kernel; longer ones are split n = n1 * n2 and run as two batched passes of those kernels
+//    around transposes (the "four-step" scheme), so every length plans;
 //  * any other length (the demos use 480 and 482: fftc/main.c:137, fir/src/main.c:154)
 //    runs Bluestein's chirp-z: x[n]*c[n] convolved with conj(c) through two
 //    power-of-two transforms of length M >= 2n-1, c[n] = exp(-i*pi*n^2/N) -- in one fused
@@ -129,6 +131,44 @@ template <typename T>
 __global__ __launch_bounds__(256) void take_real_kernel(const C<T> *__restrict__ z, T *__restrict__ x, size_t total)
 {
     GRID_STRIDE(i, total) x[i] = z[i].re;
+}
+
+// ---- long power-of-two lengths: n = n1 * n2 ------------------------------------------
+
+// out[f][c][r] = in[f][r][c] (* W_n^(r c) when TWIDDLE), in: [rows][cols] per frame; 32 x 32
+// tiles through LDS so that reads and writes are both contiguous.  W_n^e is the product of two
+// table entries, A[e >> shift] = W_n^(e with its low bits cleared) and B[e & mask] (about
+// sqrt(n) entries each, computed in long double): one extra rounding, no table of n entries.
+// conj_tw conjugates the factor (backward transform).
+template <typename T, bool TWIDDLE>
+__global__ __launch_bounds__(256) void transpose_kernel(const C<T> *__restrict__ in, C<T> *__restrict__ out, unsigned rows,
+                                                        unsigned cols, const C<T> *__restrict__ twa,
+                                                        const C<T> *__restrict__ twb, unsigned shift, int conj_tw)
+{
+    __shared__ C<T> tile[32][33];
+    const size_t frame = blockIdx.z;
+    const C<T> *src = in + frame * (size_t)rows * cols;
+    C<T> *dst = out + frame * (size_t)rows * cols;
+    const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const unsigned c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned r = r0 + ty + 8 * i, c = c0 + tx;
+        C<T> v = src[(size_t)r * cols + c];
+        if constexpr (TWIDDLE) {
+            const unsigned long long e = (unsigned long long)r * c;  // < n
+            C<T> w = cmul(twa[e >> shift], twb[e & ((1ull << shift) - 1)]);
+            if (conj_tw) w.im = -w.im;
+            v = cmul(v, w);
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned c = c0 + ty + 8 * i, r = r0 + tx;
+        dst[(size_t)c * rows + r] = tile[tx][ty + 8 * i];
+    }
 }
 
 // ---- Bluestein ------------------------------------------------------------------------
@@ -324,9 +364,16 @@ struct dspmi_fft_plan {
     // even n whose half is not a power of two: real transforms run the n/2-point complex plan
     // (itself Bluestein) around the same split / merge kernels
     dspmi_fft_plan *half_plan = nullptr;
+    // power-of-two n beyond the longest single kernel: n = n1 * n2, two batched passes
+    unsigned n1 = 0, n2 = 0, tw_shift = 0;
+    const dspmi::FftKernel *kern_n1 = nullptr, *kern_n2 = nullptr;
+    void *tw_n1 = nullptr, *tw_n2 = nullptr, *tw_hi = nullptr, *tw_lo = nullptr;
+    // Bluestein whose convolution length M is itself beyond a single kernel
+    dspmi_fft_plan *plan_M = nullptr;
     // scratch, grown on demand (allocation happens in exec only when a batch outgrows it)
-    void *work[4] = {nullptr, nullptr, nullptr, nullptr};  // 0: Bluestein, 1: real transforms, 2: spectrum bins, 3: converted input
-    size_t work_bytes[4] = {0, 0, 0, 0};
+    // 0: Bluestein, 1: real transforms, 2: spectrum bins, 3: converted input, 4: long power-of-two lengths
+    void *work[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t work_bytes[5] = {0, 0, 0, 0, 0};
     char name[64] = "";
 };
 
@@ -352,6 +399,58 @@ int run_pow2(const dspmi::FftKernel *k, const void *in, void *out, const void *t
     return (stream_policy ? k->fn_stream : k->fn)(in, out, tw, batch, backward, num_cu, s);
 }
 
+// n = n1 * n2 with x[a + n1 b] and X[n2 k1 + k2]:
+//   X[n2 k1 + k2] = sum_a W_n1^(a k1) . W_n^(a k2) . sum_b x[a + n1 b] W_n2^(b k2)
+// as transpose, n1 batched n2-point transforms, transpose with the W_n^(a k2) factors, n2 batched
+// n1-point transforms, transpose.  Frames go through in groups that keep the two work images
+// within `cap` bytes.
+template <typename T>
+int four_step(dspmi_fft_plan *pl, const C<T> *in, C<T> *out, size_t batch, int backward, hipStream_t s, void *fixed_work,
+              size_t fixed_bytes)
+{
+    const size_t n = pl->n, frame_bytes = 2 * n * sizeof(C<T>);
+    size_t cap = fixed_work ? fixed_bytes : ((size_t)512 << 20);
+    if (fixed_work && frame_bytes > cap)
+        return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: one frame of n = %u needs %zu bytes of work space, the static scratch holds %zu",
+                           pl->n, frame_bytes, cap);
+    size_t group = cap / frame_bytes;
+    if (group < 1) group = 1;
+    if (group > batch) group = batch;
+    if (group > 65535) group = 65535;  // grid z
+    C<T> *w0;
+    if (fixed_work) {
+        w0 = static_cast<C<T> *>(fixed_work);
+    } else {
+        int rc = ensure_work(pl, 4, group * frame_bytes);
+        if (rc != DSPMI_OK) return rc;
+        w0 = static_cast<C<T> *>(pl->work[4]);
+    }
+    C<T> *w1 = w0 + group * n;
+    const C<T> *hi = static_cast<const C<T> *>(pl->tw_hi), *lo = static_cast<const C<T> *>(pl->tw_lo);
+    for (size_t done = 0; done < batch; done += group) {
+        const size_t g = batch - done < group ? batch - done : group;
+        const C<T> *src = in + done * n;
+        C<T> *dst = out + done * n;
+        // x as [n2][n1] -> [n1][n2]
+        hipLaunchKernelGGL((transpose_kernel<T, false>), dim3(pl->n1 / 32, pl->n2 / 32, (unsigned)g), dim3(256), 0, s, src, w0, pl->n2,
+                           pl->n1, hi, lo, pl->tw_shift, 0);
+        DSPMI_HIP(hipGetLastError());
+        int rc = run_pow2(pl->kern_n2, w0, w0, pl->tw_n2, g * pl->n1, backward, pl->esz, pl->num_cu, s);
+        if (rc != DSPMI_OK) return rc;
+        // [n1][n2] -> [n2][n1], times W_n^(a k2)
+        hipLaunchKernelGGL((transpose_kernel<T, true>), dim3(pl->n2 / 32, pl->n1 / 32, (unsigned)g), dim3(256), 0, s, w0, w1, pl->n1,
+                           pl->n2, hi, lo, pl->tw_shift, backward);
+        DSPMI_HIP(hipGetLastError());
+        rc = run_pow2(pl->kern_n1, w1, w1, pl->tw_n1, g * pl->n2, backward, pl->esz, pl->num_cu, s);
+        if (rc != DSPMI_OK) return rc;
+        // [n2][n1] (k2, k1) -> [n1][n2]: X[n2 k1 + k2] in natural order
+        hipLaunchKernelGGL((transpose_kernel<T, false>), dim3(pl->n1 / 32, pl->n2 / 32, (unsigned)g), dim3(256), 0, s, w1, dst, pl->n2,
+                           pl->n1, hi, lo, pl->tw_shift, 0);
+        DSPMI_HIP(hipGetLastError());
+    }
+    return DSPMI_OK;
+}
+
 // fixed_work: work frames supplied by the caller (fixed_bytes of them) instead of the plan's
 // own buffer, which an execute may have to grow -- nothing is allocated or freed then.
 template <typename T>
@@ -359,6 +458,8 @@ int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int b
               void *fixed_work = nullptr, size_t fixed_bytes = 0)
 {
     if (pl->kern) return run_pow2(pl->kern, in, out, pl->tw_n, batch, backward, pl->esz, pl->num_cu, s);
+    if (pl->kern_n1)
+        return four_step<T>(pl, static_cast<const C<T> *>(in), static_cast<C<T> *>(out), batch, backward, s, fixed_work, fixed_bytes);
     // Bluestein: one kernel where it exists (DSPMI_BLUESTEIN_COMPOSED=1: the five separate ones)
     if (pl->blu && !getenv("DSPMI_BLUESTEIN_COMPOSED"))
         return pl->blu(in, out, pl->chirp, pl->filt, pl->tw_M, pl->n, batch, backward, pl->num_cu, s);
@@ -366,6 +467,9 @@ int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int b
     int rc = DSPMI_OK;
     C<T> *w;
     if (fixed_work) {
+        if (pl->plan_M)
+            return dspmi::fail(DSPMI_ENOSYS, "fft_exec_c2c_noalloc: n = %u runs over a %u-point convolution that needs two work "
+                               "buffers; use dspmi_fft_exec_c2c", n, M);
         if (batch > fixed_bytes / ((size_t)M * sizeof(C<T>)))
             return dspmi::fail(DSPMI_EINVAL,
                                "fft_exec_c2c_noalloc: %zu frames of n = %u need %zu work frames of %u points, the static "
@@ -377,15 +481,19 @@ int c2c_typed(dspmi_fft_plan *pl, const void *in, void *out, size_t batch, int b
         if (rc != DSPMI_OK) return rc;
         w = static_cast<C<T> *>(pl->work[0]);
     }
+    auto transform_M = [&](int back) {
+        return pl->kern_M ? run_pow2(pl->kern_M, w, w, pl->tw_M, batch, back, pl->esz, pl->num_cu, s)
+                          : c2c_typed<T>(pl->plan_M, w, w, batch, back, s);
+    };
     hipLaunchKernelGGL(bluestein_pre_kernel<T>, dim3(ew_grid(batch * M, pl->num_cu)), dim3(256), 0, s,
                        static_cast<const C<T> *>(in), static_cast<const C<T> *>(pl->chirp), w, n, M, batch, backward);
     DSPMI_HIP(hipGetLastError());
-    rc = run_pow2(pl->kern_M, w, w, pl->tw_M, batch, 0, pl->esz, pl->num_cu, s);
+    rc = transform_M(0);
     if (rc != DSPMI_OK) return rc;
     hipLaunchKernelGGL(bluestein_mul_kernel<T>, dim3(ew_grid(batch * M, pl->num_cu)), dim3(256), 0, s, w,
                        static_cast<const C<T> *>(pl->filt), M, batch);
     DSPMI_HIP(hipGetLastError());
-    rc = run_pow2(pl->kern_M, w, w, pl->tw_M, batch, 1, pl->esz, pl->num_cu, s);
+    rc = transform_M(1);
     if (rc != DSPMI_OK) return rc;
     hipLaunchKernelGGL(bluestein_post_kernel<T>, dim3(ew_grid(batch * n, pl->num_cu)), dim3(256), 0, s, w,
                        static_cast<const C<T> *>(pl->chirp), static_cast<C<T> *>(out), n, M, batch, backward);
@@ -411,8 +519,10 @@ int setup_bluestein(dspmi_fft_plan *pl)
     }
     int rc = upload<T>(&pl->chirp, c);
     if (rc == DSPMI_OK) rc = upload<T>(&pl->filt, b);
-    if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_M, M, pl->precision);
-    if (rc == DSPMI_OK) rc = pl->kern_M->fn(pl->filt, pl->filt, pl->tw_M, 1, 0, pl->num_cu, nullptr);
+    if (rc == DSPMI_OK && pl->kern_M) rc = upload_twiddles(&pl->tw_M, M, pl->precision);
+    if (rc == DSPMI_OK)
+        rc = pl->kern_M ? pl->kern_M->fn(pl->filt, pl->filt, pl->tw_M, 1, 0, pl->num_cu, nullptr)
+                        : c2c_typed<T>(pl->plan_M, pl->filt, pl->filt, 1, 0, nullptr);
     if (rc == DSPMI_OK) DSPMI_HIP(hipStreamSynchronize(nullptr));
     return rc;
 }
@@ -615,24 +725,38 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
 {
     if (!plan || n == 0) return dspmi::fail(DSPMI_EINVAL, "fft_create: null plan pointer or n == 0");
     if (precision != DSPMI_F32 && precision != DSPMI_F64) return dspmi::fail(DSPMI_EINVAL, "fft_create: bad precision");
-    const char *pname = precision == DSPMI_F64 ? "f64" : "f32";
-    const dspmi::FftKernel *k = nullptr, *kh = nullptr, *kM = nullptr;
-    unsigned M = 0;
+    // the twiddle table of a plan has n entries: 2^24 points (256 MiB in double) is where this stops
+    constexpr unsigned kMaxN = 1u << 24;
+    if (n > kMaxN) return dspmi::fail(DSPMI_ENOSYS, "fft_create: n = %u exceeds the longest supported transform (%u)", n, kMaxN);
+    const dspmi::FftKernel *k = nullptr, *kh = nullptr, *kM = nullptr, *k1 = nullptr, *k2 = nullptr;
+    unsigned M = 0, n1 = 0, n2 = 0;
+    bool sub_M = false, sub_half = false;
     if (n > 1) {
         if (is_pow2(n)) {
             k = dspmi::fft_find(n, precision);
-            if (!k) return dspmi::fail(DSPMI_ENOSYS, "fft_create: no %s kernel for n = %u", pname, n);
+            if (!k) {
+                // n = n1 * n2, n1 <= n2, each with a kernel of its own
+                unsigned lg = 0;
+                while ((1u << lg) < n) lg++;
+                n1 = 1u << (lg / 2);
+                n2 = n / n1;
+                k1 = dspmi::fft_find(n1, precision);
+                k2 = dspmi::fft_find(n2, precision);
+                if (!k1 || !k2 || n1 < 32)
+                    return dspmi::fail(DSPMI_ENOSYS, "fft_create: no kernels to split n = %u as %u x %u", n, n1, n2);
+            }
         } else {
-            // the convolution length must cover 2n-1 points and fit the longest kernel
-            if (n > (1u << 20)) return dspmi::fail(DSPMI_ENOSYS, "fft_create: n = %u is not a power of two and too long", n);
+            // Bluestein: a convolution of M >= 2n-1 points
+            if (n > kMaxN / 4) return dspmi::fail(DSPMI_ENOSYS, "fft_create: n = %u is not a power of two and too long", n);
             M = 1;
             while (M < 2 * n - 1) M <<= 1;
             kM = dspmi::fft_find(M, precision);
-            if (!kM)
-                return dspmi::fail(DSPMI_ENOSYS, "fft_create: n = %u needs a %u-point %s transform, which no kernel covers",
-                                   n, M, pname);
+            sub_M = !kM;
         }
-        if (n % 2 == 0 && n >= 4 && is_pow2(n / 2)) kh = dspmi::fft_find(n / 2, precision);
+        if (n % 2 == 0 && n >= 4) {
+            if (is_pow2(n / 2)) kh = dspmi::fft_find(n / 2, precision);
+            sub_half = !kh;  // the n/2-point complex transform is a plan of its own (any-length or split)
+        }
     }
     if (device < 0) DSPMI_HIP(hipGetDevice(&device));
     int prev = 0;
@@ -646,11 +770,17 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     pl->kern = k;
     pl->kern_half = kh;
     pl->kern_M = kM;
+    pl->kern_n1 = k1;
+    pl->kern_n2 = k2;
+    pl->n1 = n1;
+    pl->n2 = n2;
     if (kM) pl->blu = dspmi::bluestein_find(M, precision);
     pl->M = M;
     if (k) snprintf(pl->name, sizeof pl->name, "%s", k->name);
+    else if (k1) snprintf(pl->name, sizeof pl->name, "fft_%s_n%u_as_%ux%u", precision == DSPMI_F64 ? "f64" : "f32", n, n1, n2);
     else if (kM && pl->blu) snprintf(pl->name, sizeof pl->name, "bluestein_n%u_m%u_one_kernel", n, M);
     else if (kM) snprintf(pl->name, sizeof pl->name, "bluestein_n%u_via_%s", n, kM->name);
+    else if (M) snprintf(pl->name, sizeof pl->name, "bluestein_n%u_m%u_split", n, M);
     else snprintf(pl->name, sizeof pl->name, "fft_n1");
     hipDeviceProp_t prop;
     int rc = DSPMI_OK;
@@ -662,8 +792,23 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     }
     if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n, n, precision);
     if (rc == DSPMI_OK && kh) rc = upload_twiddles(&pl->tw_half, n / 2, precision);
-    if (rc == DSPMI_OK && kM) rc = precision == DSPMI_F64 ? setup_bluestein<double>(pl) : setup_bluestein<float>(pl);
-    if (rc == DSPMI_OK && kM && n % 2 == 0 && n >= 4 && !is_pow2(n / 2)) rc = dspmi_fft_create(&pl->half_plan, n / 2, precision, device);
+    if (rc == DSPMI_OK && k1) {
+        // W_n^e = hi[e >> shift] * lo[e & mask]
+        unsigned lg = 0;
+        while ((1u << lg) < n) lg++;
+        pl->tw_shift = (lg + 1) / 2;
+        rc = upload_twiddles(&pl->tw_n1, n1, precision);
+        if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n2, n2, precision);
+        if (rc == DSPMI_OK)
+            rc = precision == DSPMI_F64 ? upload<double>(&pl->tw_hi, unit_circle<double>(n >> pl->tw_shift, 1))
+                                        : upload<float>(&pl->tw_hi, unit_circle<float>(n >> pl->tw_shift, 1));
+        if (rc == DSPMI_OK)
+            rc = precision == DSPMI_F64 ? upload<double>(&pl->tw_lo, unit_circle<double>(1u << pl->tw_shift, n >> pl->tw_shift))
+                                        : upload<float>(&pl->tw_lo, unit_circle<float>(1u << pl->tw_shift, n >> pl->tw_shift));
+    }
+    if (rc == DSPMI_OK && sub_M) rc = dspmi_fft_create(&pl->plan_M, M, precision, device);
+    if (rc == DSPMI_OK && M) rc = precision == DSPMI_F64 ? setup_bluestein<double>(pl) : setup_bluestein<float>(pl);
+    if (rc == DSPMI_OK && sub_half) rc = dspmi_fft_create(&pl->half_plan, n / 2, precision, device);
     (void)hipSetDevice(prev);
     if (rc != DSPMI_OK) {
         dspmi_fft_destroy(pl);
@@ -677,7 +822,9 @@ int dspmi_fft_destroy(dspmi_fft_t plan)
 {
     if (!plan) return DSPMI_OK;
     if (plan->half_plan) (void)dspmi_fft_destroy(plan->half_plan);
-    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->work[0], plan->work[1], plan->work[2], plan->work[3]};
+    if (plan->plan_M) (void)dspmi_fft_destroy(plan->plan_M);
+    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->tw_n1, plan->tw_n2, plan->tw_hi, plan->tw_lo,
+                    plan->work[0], plan->work[1], plan->work[2], plan->work[3], plan->work[4]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete plan;

@@ -143,8 +143,11 @@ typedef struct { double re, im; } dspmi_c64;
  * (fftc/main.c:33-35, fft/src/main.c:156-166, util/filter/filter.c:86-103). */
 typedef struct dspmi_fft_plan *dspmi_fft_t;
 
-/* n: transform length (complex points, or real samples for r2c/c2r).
- * Returns DSPMI_ENOSYS for a length no kernel covers. */
+/* n: transform length (complex points, or real samples for r2c/c2r): any length up to 2^24
+ * points, 2^22 when it is not a power of two (the reference's tools transform whatever window
+ * their input holds, util/fft/fft.c:321-352); DSPMI_ENOSYS beyond.  Powers of two up to 16384
+ * (f32) / 8192 (f64) run as one kernel, longer ones as two batched passes of those kernels
+ * (n = n1 * n2), other lengths through a chirp-z convolution of a power-of-two length. */
 int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device);
 int dspmi_fft_destroy(dspmi_fft_t plan);
 
@@ -158,13 +161,15 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
 /* dspmi_fft_exec_c2c for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
  * the reference.  Same arguments and results as dspmi_fft_exec_c2c; the difference is where
- * the multi-kernel any-length transform (double precision, lengths that are not a power of
- * two) keeps its work frames: not in the plan's own buffer, which an execute may have to
- * grow, but in a static device array of DSPMI_NOALLOC_SCRATCH_BYTES that every GPU the
- * library runs on holds until the process ends.  The call performs no hipMalloc / hipFree.
- * A batch whose work frames (batch * M * 16 bytes, M = the power of two >= 2n-1) exceed the
- * array is refused with DSPMI_EINVAL.  All calls on one GPU share the array: calls that
- * overlap in time on one GPU (two streams, two threads) race, whatever plans they use. */
+ * the multi-kernel transforms keep their work frames (the any-length transform in double
+ * precision: batch * M * 16 bytes, M = the power of two >= 2n-1; powers of two beyond the
+ * longest single kernel: 2 * n points per frame, frames going through in groups that fit):
+ * not in the plan's own buffer, which an execute may have to grow, but in a static device
+ * array of DSPMI_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the
+ * process ends.  The call performs no hipMalloc / hipFree.  Work frames that exceed the array
+ * are refused with DSPMI_EINVAL (a length that needs both kinds of work space at once with
+ * DSPMI_ENOSYS).  All calls on one GPU share the array: calls that overlap in time on one GPU
+ * (two streams, two threads) race, whatever plans they use. */
 #define DSPMI_NOALLOC_SCRATCH_BYTES (16u << 20)
 int dspmi_fft_exec_c2c_noalloc(dspmi_fft_t plan, const void *in, void *out, size_t batch,
                                int sign, void *stream);

@@ -280,10 +280,11 @@ def test_filter_one_kernel_form_matches_the_composition(n, batch, monkeypatch):
 
 
 def test_lengths_no_kernel_covers_are_refused():
-    """Plan creation answers -ENOSYS (with a message) instead of planning something it cannot run."""
+    """Plan creation answers -ENOSYS (with a message) instead of planning something it cannot run:
+    beyond 2^24 points (2^22 when the length is not a power of two)."""
     import ctypes as C
     L = dsp_amd.lib()
-    for n, prec in ((32768, 0), (9000, 0), ((1 << 31) - 100, 0), ((1 << 31) + 1, 0), (16384, 1), (5000, 1)):
+    for n, prec in (((1 << 24) + 2, 0), (1 << 25, 1), ((1 << 22) + 1, 0), ((1 << 31) - 100, 0), ((1 << 31) + 1, 1)):
         h = C.c_void_p()
         rc = L.dspmi_fft_create(C.byref(h), n, prec, -1)
         assert rc == -38 and not h.value, (n, prec, rc)
@@ -344,3 +345,64 @@ def test_batched_real_transforms_any_length(dtype, n, batch):
         xf = xd[f].double().cpu().numpy()
         assert rel_l2(got[f], oracle.fft_r2c(xf)) <= tol, (f, rel_l2(got[f], oracle.fft_r2c(xf)))
         assert rel_l2(back[f], xf) <= tol
+
+
+# ---- lengths beyond the longest single-workgroup kernel: n = n1 * n2 in two batched passes ----
+
+@pytest.mark.parametrize("dtype,n,batch", [("f32", 32768, 3), ("f32", 1 << 17, 2), ("f32", 1 << 20, 1),
+                                           ("f64", 16384, 3), ("f64", 65536, 2), ("f64", 1 << 20, 1)])
+def test_c2c_long_powers_of_two(dtype, n, batch):
+    rng = np.random.default_rng(n + batch)
+    ct = np.complex128 if dtype == "f64" else np.complex64
+    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(ct)
+    plan = dsp_amd.FftPlan(n, dtype)
+    assert "_as_" in plan.variant
+    zd = torch.from_numpy(z).cuda()
+    tol = TOL_F64 if dtype == "f64" else TOL_FFT
+    for sign in (dsp_amd.FORWARD, dsp_amd.BACKWARD):
+        got = plan.c2c(zd, sign).cpu().numpy()
+        for f in range(batch):
+            want = oracle.dft(z[f].astype(np.complex128), sign, "radix2")
+            assert rel_l2(got[f], want) <= tol, (dtype, n, sign, f, rel_l2(got[f], want))
+    # in place, and the round trip n * identity
+    buf = zd.clone()
+    plan.c2c(buf, dsp_amd.FORWARD, out=buf)
+    plan.c2c(buf, dsp_amd.BACKWARD, out=buf)
+    assert rel_l2(buf.cpu().numpy() / n, z) <= 4 * tol
+
+
+@pytest.mark.parametrize("dtype,n", [("f64", 5000), ("f64", 12000), ("f32", 9000), ("f32", 12000)])
+def test_c2c_any_length_over_a_split_convolution(dtype, n):
+    """Lengths whose chirp-z convolution (M >= 2n-1 points) is itself beyond a single kernel."""
+    rng = np.random.default_rng(n)
+    ct = np.complex128 if dtype == "f64" else np.complex64
+    z = (rng.uniform(-1, 1, (2, n)) + 1j * rng.uniform(-1, 1, (2, n))).astype(ct)
+    plan = dsp_amd.FftPlan(n, dtype)
+    assert "split" in plan.variant
+    zd = torch.from_numpy(z).cuda()
+    for sign in (dsp_amd.FORWARD, dsp_amd.BACKWARD):
+        got = plan.c2c(zd, sign).cpu().numpy()
+        want = oracle.dft(z[1].astype(np.complex128), sign, "direct")
+        assert rel_l2(got[1], want) <= (TOL_F64 if dtype == "f64" else TOL_FFT)
+
+
+@pytest.mark.parametrize("n", [20000, 32768, 48000, 100000])
+def test_double_wrappers_on_long_windows(n):
+    """util/fft and util/filter transform whatever window the input table holds -- a second at
+    48 kHz is 48000 samples (util/fft/fft.c:321-352, util/filter/filter.c:319-365)."""
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, n)
+    bins = dsp_amd.fft_r2c(x)
+    if n <= 20000:
+        want = oracle.fft_r2c(x)        # the checker's own transform (O(n^2) in long double off powers of two)
+    elif n & (n - 1) == 0:
+        want = oracle.dft(x.astype(np.complex128), -1, "radix2")[:n // 2 + 1]
+    else:
+        want = np.fft.rfft(x)           # numpy's pocketfft as the cross-check at sizes the O(n^2) checker takes minutes for
+    assert rel_l2(bins, want) <= TOL_F64
+    gains = np.where(np.arange(n // 2 + 1) < n // 8, 1.0, 0.25)
+    y = dsp_amd.filter(x, gains)
+    want_y = oracle.filter(x, gains) if n <= 20000 else np.fft.irfft(np.fft.rfft(x) * gains, n)
+    assert rel_l2(y, want_y) <= TOL_F64
+    # properties that need no checker: the filter is linear and gain 1 everywhere returns the input
+    assert rel_l2(dsp_amd.filter(x, np.ones(n // 2 + 1)), x) <= TOL_F64
