@@ -190,7 +190,7 @@ __device__ __forceinline__ O tone_out(double v)
     }
 }
 
-template <typename O>
+template <typename O, int MAXT>
 __global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned nchan,
                                                      unsigned ntone, double *__restrict__ w, const double *__restrict__ dw,
                                                      const double *__restrict__ amp, const double *__restrict__ phi,
@@ -200,7 +200,6 @@ __global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x
     const unsigned lane = threadIdx.x;
     const unsigned c = blockIdx.x * 64 + lane;
     const bool live = c < nchan;
-    constexpr int MAXT = 8;
     double wl[MAXT], dwl[MAXT], al[MAXT], pl[MAXT];
 #pragma unroll
     for (int j = 0; j < MAXT; j++) {
@@ -317,103 +316,120 @@ __global__ __launch_bounds__(64) void tonegen_finish_kernel(double *__restrict__
 // applied as a first-order correction.
 constexpr unsigned kToneSteps = 256;                // samples per lane
 constexpr unsigned kToneRange = 64 * kToneSteps;    // samples per wave
+constexpr unsigned kToneStepsGrouped = 32;          // samples per lane when the tones go through in groups
 
-// MAXT: tones the instantiation can hold (the loops over tones are unrolled to it)
-template <typename O, int MAXT>
+// MAXT: tones the instantiation holds at a time (the loops over tones are unrolled to it).
+// STEPS: samples per lane, 64 * STEPS per wave.  GROUPS: more than MAXT tones (the reference's
+// generator holds up to 32, tonegen/tonegen.h:14-19) go through in groups of MAXT; a sample's
+// running sum waits in LDS between groups, in double, so every sample still adds its tones in
+// the reference's order (tonegen/tonegen.c:31-37) and rounds once.
+template <typename O, int MAXT, int STEPS, bool GROUPS>
 __global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned ntone,
                                                            const double *__restrict__ w, const double *__restrict__ dw,
                                                            const double *__restrict__ amp, const double *__restrict__ phi,
                                                            int use_sin)
 {
+    constexpr unsigned RANGE = 64 * STEPS;
+    __shared__ double partial[GROUPS ? RANGE : 1];
     const unsigned lane = threadIdx.x;
-    const unsigned nrange = (n + kToneRange - 1) / kToneRange;
+    const unsigned nrange = (n + RANGE - 1) / RANGE;
     const unsigned chan = blockIdx.x / nrange;
-    const size_t first = (size_t)(blockIdx.x - chan * nrange) * kToneRange;
-    const unsigned len = (unsigned)min((size_t)kToneRange, (size_t)n - first);
-    double A[MAXT], dl[MAXT], al[MAXT], pl[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; j++) {
-        const bool on = j < (int)ntone;
-        const size_t s = (size_t)chan * ntone + j;
-        dl[j] = on ? dw[s] : 0.0;
-        A[j] = on ? advance(w[s], dl[j], first) : 0.0;  // angle at the range's first sample: the same for every lane
-        al[j] = on ? amp[s] : 0.0;
-        pl[j] = (on && !use_sin) ? phi[s] : 0.0;
-    }
+    const size_t first = (size_t)(blockIdx.x - chan * nrange) * RANGE;
+    const unsigned len = (unsigned)min((size_t)RANGE, (size_t)n - first);
     O *xrow = x + (size_t)chan * x_stride + first;
 
-    unsigned pos = 0;
-    while (pos < len) {
-        // the segment: as far as every tone's run reaches (one sample where a tone needs a real addition)
-        unsigned seg = len - pos;
-        double step[MAXT];
-        bool real_add[MAXT];
+    for (unsigned j0 = 0; j0 < (GROUPS ? ntone : 1u); j0 += MAXT) {
+        const int nt = GROUPS ? (int)min((unsigned)MAXT, ntone - j0) : (int)ntone;  // tones of this group
+        const bool first_group = j0 == 0, last_group = !GROUPS || j0 + MAXT >= ntone;
+        double A[MAXT], dl[MAXT], al[MAXT], pl[MAXT];
 #pragma unroll
         for (int j = 0; j < MAXT; j++) {
-            step[j] = 0.0;
-            real_add[j] = false;
-            if (j < (int)ntone) {
-                const unsigned long long run = (A[j] >= 0.0 && dl[j] > 0.0) ? fixed_run(A[j], dl[j], step[j]) : 0;
-                real_add[j] = run == 0;
-                if (run < seg) seg = run == 0 ? 1 : (unsigned)run;
-            }
+            const bool on = j < nt;
+            const size_t s = (size_t)chan * ntone + j0 + j;
+            dl[j] = on ? dw[s] : 0.0;
+            A[j] = on ? advance(w[s], dl[j], first) : 0.0;  // angle at the range's first sample: the same for every lane
+            al[j] = on ? amp[s] : 0.0;
+            pl[j] = (on && !use_sin) ? phi[s] : 0.0;
         }
-        // this lane's samples in the segment: k = k0, k0 + 64, ... < pos + seg
-        const unsigned off = (lane - pos) & 63;  // k0 - pos
-        double a0[MAXT], st64[MAXT], cs[MAXT], sn[MAXT], cd[MAXT], sd[MAXT];
-        if (off < seg) {
+
+        unsigned pos = 0;
+        while (pos < len) {
+            // the segment: as far as every tone's run reaches (one sample where a tone needs a real addition)
+            unsigned seg = len - pos;
+            double step[MAXT];
+            bool real_add[MAXT];
 #pragma unroll
             for (int j = 0; j < MAXT; j++) {
-                a0[j] = fma((double)off, step[j], A[j]);  // exact
-                st64[j] = 64.0 * step[j];
-                // cos / sin of the exact angle a + phase: of the rounded sum, corrected by its residual
-                const double sum = a0[j] + pl[j];
-                const double bb = sum - a0[j];
-                const double err = (a0[j] - (sum - bb)) + (pl[j] - bb);  // a + phase = sum + err
-                const double c0 = tone_cos(sum), s0 = tone_sin(sum);
-                cs[j] = fma(-err, s0, c0);
-                sn[j] = fma(err, c0, s0);
-                if (seg > 64) {
-                    cd[j] = tone_cos(st64[j]);
-                    sd[j] = tone_sin(st64[j]);
-                } else {
-                    cd[j] = 1.0;  // a single sample per lane: never turned
-                    sd[j] = 0.0;
+                step[j] = 0.0;
+                real_add[j] = false;
+                if (j < nt) {
+                    const unsigned long long run = (A[j] >= 0.0 && dl[j] > 0.0) ? fixed_run(A[j], dl[j], step[j]) : 0;
+                    real_add[j] = run == 0;
+                    if (run < seg) seg = run == 0 ? 1 : (unsigned)run;
                 }
-                if (j >= (int)ntone) al[j] = cs[j] = sn[j] = 0.0;  // idle slots add nothing
             }
-            unsigned i = 0;
-            for (unsigned k = pos + off; k < pos + seg; k += 64, i++) {
-                double v = 0.0;
+            // this lane's samples in the segment: k = k0, k0 + 64, ... < pos + seg
+            const unsigned off = (lane - pos) & 63;  // k0 - pos
+            double a0[MAXT], st64[MAXT], cs[MAXT], sn[MAXT], cd[MAXT], sd[MAXT];
+            if (off < seg) {
 #pragma unroll
                 for (int j = 0; j < MAXT; j++) {
-                    if (use_sin) {
-                        v += sn[j];
+                    a0[j] = fma((double)off, step[j], A[j]);  // exact
+                    st64[j] = 64.0 * step[j];
+                    // cos / sin of the exact angle a + phase: of the rounded sum, corrected by its residual
+                    const double sum = a0[j] + pl[j];
+                    const double bb = sum - a0[j];
+                    const double err = (a0[j] - (sum - bb)) + (pl[j] - bb);  // a + phase = sum + err
+                    const double c0 = tone_cos(sum), s0 = tone_sin(sum);
+                    cs[j] = fma(-err, s0, c0);
+                    sn[j] = fma(err, c0, s0);
+                    if (seg > 64) {
+                        cd[j] = tone_cos(st64[j]);
+                        sd[j] = tone_sin(st64[j]);
                     } else {
-                        double c = cs[j];
-                        if (pl[j] != 0.0) {
-                            // the reference's angle is fl(a_k + phase) = (a_k + phase) - err
-                            const double ak = fma((double)i, st64[j], a0[j]);
-                            const double sum = ak + pl[j];
-                            const double bb = sum - ak;
-                            const double err = (ak - (sum - bb)) + (pl[j] - bb);
-                            c = fma(err, sn[j], c);
-                        }
-                        v += al[j] * c;
+                        cd[j] = 1.0;  // a single sample per lane: never turned
+                        sd[j] = 0.0;
                     }
-                    const double cn = fma(cs[j], cd[j], -(sn[j] * sd[j]));
-                    sn[j] = fma(sn[j], cd[j], cs[j] * sd[j]);
-                    cs[j] = cn;
                 }
-                xrow[k] = tone_out<O>(v);
-            }
-        }
-        // every lane moves the angles to the next segment's first sample
+                unsigned i = 0;
+                for (unsigned k = pos + off; k < pos + seg; k += 64, i++) {
+                    double v = 0.0;
+                    if constexpr (GROUPS) {
+                        if (!first_group) v = partial[k];  // the lane's own slot: k = lane (mod 64) in every group
+                    }
 #pragma unroll
-        for (int j = 0; j < MAXT; j++) {
-            if (j < (int)ntone) A[j] = real_add[j] ? A[j] + dl[j] : fma((double)seg, step[j], A[j]);
+                    for (int j = 0; j < MAXT; j++) {
+                        if (j < nt) {  // an idle slot must not add anything, not even +0.0 to a -0.0 sum
+                            if (use_sin) {
+                                v += sn[j];
+                            } else {
+                                double c = cs[j];
+                                if (pl[j] != 0.0) {
+                                    // the reference's angle is fl(a_k + phase) = (a_k + phase) - err
+                                    const double ak = fma((double)i, st64[j], a0[j]);
+                                    const double sum = ak + pl[j];
+                                    const double bb = sum - ak;
+                                    const double err = (ak - (sum - bb)) + (pl[j] - bb);
+                                    c = fma(err, sn[j], c);
+                                }
+                                v += al[j] * c;
+                            }
+                        }
+                        const double cn = fma(cs[j], cd[j], -(sn[j] * sd[j]));
+                        sn[j] = fma(sn[j], cd[j], cs[j] * sd[j]);
+                        cs[j] = cn;
+                    }
+                    if (last_group) xrow[k] = tone_out<O>(v);
+                    else if constexpr (GROUPS) partial[k] = v;
+                }
+            }
+            // every lane moves the angles to the next segment's first sample
+#pragma unroll
+            for (int j = 0; j < MAXT; j++) {
+                if (j < nt) A[j] = real_add[j] ? A[j] + dl[j] : fma((double)seg, step[j], A[j]);
+            }
+            pos += seg;
         }
-        pos += seg;
     }
 }
 
@@ -466,21 +482,27 @@ int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned nton
 {
     if (n == 0 || nchan == 0) return DSPMI_OK;
     if (!x || !w || !dw || (!use_sin && (!amp || !phi))) return dspmi::fail(DSPMI_EINVAL, "tonegen: null buffer");
-    if (ntone == 0 || ntone > 8) return dspmi::fail(DSPMI_ENOSYS, "tonegen: 1..8 tones per channel on the device (got %u)", ntone);
+    if (ntone == 0 || ntone > 32)
+        return dspmi::fail(DSPMI_ENOSYS, "tonegen: 1..32 tones per channel, as the reference's generator holds (got %u)", ntone);
     if (x_stride < n) return dspmi::fail(DSPMI_EINVAL, "tonegen: x_stride < n");
     if (use_sin && (!amp || !phi)) amp = phi = dw;  // never read in the sine form
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (flags & DSPMI_TONEGEN_SEQUENTIAL) {
-        hipLaunchKernelGGL(tonegen_kernel<O>, dim3((nchan + 63) / 64), dim3(64), 0, s, x, x_stride, n, nchan, ntone, w, dw, amp, phi,
-                           use_sin);
+        auto seq = ntone <= 8 ? tonegen_kernel<O, 8> : tonegen_kernel<O, 32>;
+        hipLaunchKernelGGL(seq, dim3((nchan + 63) / 64), dim3(64), 0, s, x, x_stride, n, nchan, ntone, w, dw, amp, phi, use_sin);
         DSPMI_HIP(hipGetLastError());
         return DSPMI_OK;
     }
     const unsigned nseq = nchan * ntone;
-    const unsigned long long nrange = (n + kToneRange - 1) / kToneRange;
+    // up to 8 tones: 16384 samples per wave; more: groups of 8 tones over 2048-sample ranges
+    // (a range's running sums wait in 16 KB of LDS between groups)
+    const unsigned range = ntone <= 8 ? kToneRange : 64 * kToneStepsGrouped;
+    const unsigned long long nrange = (n + range - 1) / range;
     if (nrange * nchan > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "tonegen: too many sample ranges for one launch");
-    auto kern = ntone == 1 ? tonegen_range_kernel<O, 1> : ntone == 2 ? tonegen_range_kernel<O, 2>
-              : ntone <= 4 ? tonegen_range_kernel<O, 4> : tonegen_range_kernel<O, 8>;
+    auto kern = ntone == 1 ? tonegen_range_kernel<O, 1, kToneSteps, false> : ntone == 2 ? tonegen_range_kernel<O, 2, kToneSteps, false>
+              : ntone <= 4 ? tonegen_range_kernel<O, 4, kToneSteps, false>
+              : ntone <= 8 ? tonegen_range_kernel<O, 8, kToneSteps, false>
+                           : tonegen_range_kernel<O, 8, kToneStepsGrouped, true>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nrange * nchan)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp, phi, use_sin);
     hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
     DSPMI_HIP(hipGetLastError());

@@ -25,10 +25,13 @@
  * Threads: any number of threads may create, execute and destroy DIFFERENT plans
  * concurrently.  One plan must not be executed from two threads (or on two
  * streams) at once: FFT and overlap-save plans own scratch buffers that an
- * execute may grow and that consecutive kernels of one execute share.  FIR
- * plans hold only the taps and may be shared freely.  Every execute is
- * asynchronous on the stream given; destroying a plan while its work is still
- * queued is the caller's error, as with fftw_destroy_plan.
+ * execute may grow and that consecutive kernels of one execute share -- and an
+ * f32 FIR plan of 64 taps or more owns an overlap-save plan, so the same rule
+ * holds for it.  Only FIR plans without one (f64 plans, f32 plans of fewer than 64
+ * taps or created with DSPMI_FIR_VARIANT=mfma / valu) hold nothing but their taps
+ * and may be shared freely.  Every execute is asynchronous on the stream given;
+ * destroying a plan while its work is still queued is the caller's error, as with
+ * fftw_destroy_plan.
  */
 #ifndef DSPMI_H_INCLUDED
 #define DSPMI_H_INCLUDED
@@ -255,7 +258,7 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
  * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from
  * call to call.  use_sin != 0 selects the unit-amplitude sine form of fft/src/main.c:281-290
- * (amp and phi unused).  ntone <= 8.
+ * (amp and phi unused).  ntone <= 32, the reference's limit (tonegen/tonegen.h:14-19).
  * The call is parallel in time as well as over channels: the running angle at the start of
  * every 16384-sample range is computed exactly (the rounded additions inside one binade of the
  * angle are a fixed integer step, so they are applied in one go; additions that cross a binade

@@ -111,6 +111,35 @@ def test_tonegen_matches_recurrence_and_continues():
     assert np.abs(got - want.astype(np.float32)).max() <= 3e-7
 
 
+@pytest.mark.parametrize("ntone", [9, 17, 32])
+def test_tonegen_up_to_the_reference_limit_of_32_tones(ntone):
+    """tonegen_t holds up to 32 tones (tonegen/tonegen.h:14-19); beyond 8 the device generator
+    takes them in groups, every sample still adding its tones in the reference's order."""
+    fs, nchan = 44100.0, 6
+    rng = np.random.default_rng(ntone)
+    freqs = rng.uniform(20.0, 20000.0, (nchan, ntone))
+    amps = rng.uniform(0.1, 100.0, (nchan, ntone))
+    phis = rng.uniform(-3.0, 3.0, (nchan, ntone))
+    phis[:, ::3] = 0.0
+    g_par, g_seq = dsp_amd.ToneGen(fs, freqs, amps, phis), dsp_amd.ToneGen(fs, freqs, amps, phis)
+    outs = []
+    for n in (700, 5000, 1, 20000):
+        a, b = g_par.read(n), g_seq.read(n, sequential=True)
+        assert same_samples(b, a, float(amps.sum(axis=1).max())), n
+        outs.append(a.cpu().numpy())
+    assert torch.equal(g_par.w, g_seq.w)
+    got = np.concatenate(outs, axis=1)
+    for c in (0, nchan - 1):
+        t = oracle.Tonegen()
+        for j in range(ntone):
+            t.add(fs, freqs[c, j], amps[c, j], phis[c, j])
+        want = t.read(got.shape[1])
+        scale = np.abs(want).max()
+        assert np.abs(got[c] - want.astype(np.float32)).max() <= 2e-7 * scale
+    with pytest.raises(dsp_amd.DspmiError):
+        dsp_amd.ToneGen(fs, np.ones((1, 33))).read(10)
+
+
 def test_chain_streaming_matches_oracle_end_to_end():
     """tonegen -> 16-tap FIR (alsa/main.c:389-407) -> N=4096 r2c -> |X|/sum, 3 chunks of 2 frames."""
     fs, nchan, nfft, frames_per_chunk, nchunks = 48000.0, 5, 4096, 2, 3
