@@ -1134,9 +1134,9 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
     a.nchan = o.nchan;
     const size_t total = (size_t)a.nchan * a.npair;
     if (total == 0) return DSPMI_OK;
-    // one workgroup per block pair: the dispatcher hands the next one to whichever CU is free
-    (void)num_cu;
-    const size_t grid = total > 0x7fffffffu ? 0x7fffffffu : total;
+    // one workgroup fits a CU: a resident set that strides over the block pairs (0.286 ms against
+    // 0.294 with one workgroup per pair on 2^26 samples -- the twiddle tables are set up once)
+    const size_t grid = total < (size_t)num_cu ? total : (size_t)num_cu;
     // tables: exp(-2 pi i k / 1024), k < 1024, then the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]
     const C<float> *tw_sub = static_cast<const C<float> *>(tables);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, a, tw_sub, tw_sub + NS);
