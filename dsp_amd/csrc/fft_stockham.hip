@@ -783,6 +783,7 @@ struct OlsArgs {
     const C<float> *H;  // FFT_N(taps) / N
     size_t x_stride, y_stride, hist_stride;
     unsigned nx, nh, L, nblk, npair, nchan;
+    unsigned stagger = 0;  // ols_wave_kernel: spread of the workgroups' start times, in clock ticks
 };
 
 // The radix list is symmetric (R0 == last radix), so the positions a lane holds after the
@@ -981,6 +982,21 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
 
     const long nx = a.nx, nh = a.nh, L = a.L;
     const size_t total = (size_t)a.nchan * a.npair;
+    if (a.stagger) {
+        // Workgroups that start together stay in step: every CU stores its 192 KB and loads its
+        // 256 KB at the same moment -- a burst that HBM takes ~20 us to move while every CU waits --
+        // and then every CU computes for 30 us while HBM idles (measured with per-phase
+        // timestamps: 12 us from the top of a block pair until its input has arrived).  Spreading
+        // the start times over about a period keeps the phases apart for the first several pairs
+        // (they drift back into step after about ten).  The workgroups that stride over one pair
+        // more than the others start at once; the others share the later starts, which costs
+        // nothing at the end (their last round is the one they do not have).
+        const unsigned extra = (unsigned)(total % gridDim.x);
+        const unsigned long long wait =
+            blockIdx.x < extra ? 0 : (unsigned long long)a.stagger * (blockIdx.x - extra + (extra ? 1 : 0)) / (gridDim.x - extra);
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);  // bounded by the clock
+    }
     for (size_t frame = blockIdx.x; frame < total; frame += gridDim.x) {
         const size_t c = frame / a.npair;
         const unsigned p = (unsigned)(frame - c * a.npair);
@@ -1137,6 +1153,16 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
     // one workgroup fits a CU: a resident set that strides over the block pairs (0.286 ms against
     // 0.294 with one workgroup per pair on 2^26 samples -- the twiddle tables are set up once)
     const size_t grid = total < (size_t)num_cu ? total : (size_t)num_cu;
+    {
+        // start-time spread: 60000 ticks (~25 us, about 0.6 of a block pair's time) measured best
+        // on 2^26 samples (0.289 -> 0.258 ms); with every workgroup striding over the same number
+        // of pairs the spread is paid at the end, which it earns back from four rounds on
+        // (1280 pairs: 0.259 -> 0.236 ms).  DSPMI_OLS_STAGGER=<ticks> overrides, 0 turns it off.
+        const size_t rounds = total / grid;
+        const char *env = getenv("DSPMI_OLS_STAGGER");
+        a.stagger = env ? (unsigned)atoi(env) : 60000u;
+        if (rounds < 2 || (total % grid == 0 && rounds < 4)) a.stagger = 0;
+    }
     // tables: exp(-2 pi i k / 1024), k < 1024, then the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]
     const C<float> *tw_sub = static_cast<const C<float> *>(tables);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, a, tw_sub, tw_sub + NS);
