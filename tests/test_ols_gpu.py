@@ -40,8 +40,9 @@ def check_blocks(got, want, x, h, tag):
     return worst
 
 
-@pytest.mark.parametrize("nh,fft_n", [(16, 64), (127, 1024), (300, 2048), (1000, 4096), (8191, 16384), (8191, 0), (33, 0)])
-@pytest.mark.parametrize("nx,nchan", [(1, 1), (5000, 3), (40000, 2)])
+@pytest.mark.parametrize("nh,fft_n", [(16, 64), (127, 1024), (300, 2048), (1000, 4096), (8191, 16384), (8191, 0), (33, 0),
+                                      (16, 32768), (2049, 32768), (16384, 32768)])
+@pytest.mark.parametrize("nx,nchan", [(1, 1), (5000, 3), (40000, 2), (70001, 2)])
 def test_ols_matches_oracle(nh, fft_n, nx, nchan):
     rng = np.random.default_rng(nh + nx)
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
@@ -103,3 +104,22 @@ def test_ols_long_signal_round_properties():
     y = plan.exec(x).cpu().numpy()[0]
     np.testing.assert_allclose(y[12345:12345 + nh], 2.0 * h, atol=2e-7)
     assert np.abs(y[:12345]).max() < 2e-7 and np.abs(y[12345 + nh:]).max() < 2e-7
+
+
+@pytest.mark.parametrize("nh", [2049, 5000, 8191])
+def test_fir_plan_takes_the_long_block_path_with_history(nh):
+    """An f32 FIR plan of more than 2048 taps filters long rows through 32768-point blocks; rows
+    cut in chunks with carried history give the row's outputs, ragged lengths included."""
+    rng = np.random.default_rng(nh)
+    nchan, chunk = 3, 70001
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (nchan, 2 * chunk)).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert plan.variant == "fir_f32_overlap_save_n32768"
+    xd = torch.from_numpy(x).cuda()
+    first = plan.exec(xd[:, :chunk].contiguous())
+    second = plan.exec(xd[:, chunk:].contiguous(), hist=xd[:, chunk - (nh - 1):chunk].contiguous())
+    got = torch.cat([first, second], dim=1).cpu().numpy()
+    want = oracle.fir_batch_f32(x, h, 2 * chunk)
+    for c in range(nchan):
+        check_blocks(got[c], want[c], x[c], h, (nh, c))
