@@ -870,7 +870,10 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
         }
 
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
-        // spectrum times H, conjugated for the backward transform (conj . forward . conj)
+        // spectrum times H, then the backward transform as swap . forward . swap (swap exchanges
+        // the real and imaginary parts: swap(z) = i conj(z), so forward(swap(Y)) = i conj(backward(Y))
+        // = swap(backward(Y)); unlike conj . forward . conj it costs no instruction, only the names
+        // of two registers)
         {
             // laundered lane index: H[...] is the same for every frame, and hoisting its 2*P
             // values out of the frame loop would cost their registers through both transforms
@@ -881,7 +884,7 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
             for (int i = 0; i < P; i++) {
                 const C<T> hq = hp[NT * (i / R0) + (i % R0) * STEP];
                 const C<T> m = cmul(v[i], hq);
-                v[i] = {m.re, -m.im};
+                v[i] = {m.im, m.re};
             }
         }
         run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
@@ -895,8 +898,8 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
             for (int i = 0; i < P; i++) {
                 const int off = NT * (i / R0) + (i % R0) * STEP;
                 if (off >= skip) {
-                    __builtin_nontemporal_store(v[i].re, q0 + off);
-                    __builtin_nontemporal_store(-v[i].im, q1 + off);
+                    __builtin_nontemporal_store(v[i].im, q0 + off);  // swapped back: im holds the even block
+                    __builtin_nontemporal_store(v[i].re, q1 + off);
                 }
             }
         } else {
@@ -911,8 +914,8 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
                     if (j < 0) continue;
                     const C<T> q = lds[pad(m)];
                     const long o0 = (long)(2 * p) * L + j;
-                    if (o0 < nx) yrow[o0] = q.re;
-                    if (second && o0 + L < nx) yrow[o0 + L] = -q.im;
+                    if (o0 < nx) yrow[o0] = q.im;
+                    if (second && o0 + L < nx) yrow[o0 + L] = q.re;
                 }
             }
             frame_sync<NT>();
@@ -1061,15 +1064,16 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             unsigned la = lane, lh = lane, lb = lane;
             asm volatile("" : "+v"(la));
             run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, la);
-            // spectrum times H (stored row by row: H[k1 + K1 k2] at [k1][k2]), conjugated for the
-            // second transform (conj . forward . conj).  Requesting H before the transform would
-            // hide its latency but does not fit the 128 registers next to the other row.
+            // spectrum times H (stored row by row: H[k1 + K1 k2] at [k1][k2]), real and imaginary
+            // parts swapped for the second transform (backward = swap . forward . swap).
+            // Requesting H before the transform would hide its latency but does not fit the 128
+            // registers next to the other row.
             asm volatile("" : "+v"(lh));
             const C<T> *hp = a.H + (size_t)NS * (wave * SPW + s) + lh;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const C<T> m = cmul(u[s][r], hp[64 * r]);
-                u[s][r] = {m.re, -m.im};
+                u[s][r] = {m.im, m.re};
             }
             // ---- second transform: rows, stage factors, radix-K1 sum ----
             asm volatile("" : "+v"(lb));
@@ -1099,8 +1103,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
         sf.apply(v);
         dft_reg<K1, 1>(v);
 
-        // outputs j = m - (nh-1) >= 0 of each block of the pair; the result is conjugated:
-        // re belongs to the even block, -im to the odd one
+        // outputs j = m - (nh-1) >= 0 of each block of the pair; the result comes out swapped:
+        // im belongs to the even block, re to the odd one
         unsigned to = tl;
         asm volatile("" : "+v"(to));  // keeps the store predicates from being formed (and kept) early
         if (interior) {
@@ -1110,8 +1114,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
 #pragma unroll
             for (int n1 = 0; n1 < K1; n1++) {
                 if (NS * n1 >= skip) {
-                    __builtin_nontemporal_store(v[n1].re, q0 + NS * n1);
-                    __builtin_nontemporal_store(-v[n1].im, q1 + NS * n1);
+                    __builtin_nontemporal_store(v[n1].im, q0 + NS * n1);
+                    __builtin_nontemporal_store(v[n1].re, q1 + NS * n1);
                 }
             }
         } else {
@@ -1120,8 +1124,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             for (int n1 = 0; n1 < K1; n1++) {
                 const long j = (long)to + NS * n1 - (nh - 1);
                 const long o0 = (long)(2 * p) * L + j;
-                if (j >= 0 && o0 < nx) yrow[o0] = v[n1].re;
-                if (j >= 0 && second && o0 + L < nx) yrow[o0 + L] = -v[n1].im;
+                if (j >= 0 && o0 < nx) yrow[o0] = v[n1].im;
+                if (j >= 0 && second && o0 + L < nx) yrow[o0 + L] = v[n1].re;
             }
         }
     }
