@@ -721,7 +721,14 @@ int filter_typed(dspmi_fft_plan *pl, const void *in, void *out, const void *gain
 
 extern "C" {
 
-int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
+namespace {
+
+// c2c_only: a plan that another plan keeps for its complex transforms (the convolution of an
+// any-length transform, the half-length transform of a real one).  It is never asked for a real
+// transform, so it needs neither a half-length plan of its own nor, when it is split or any-length
+// itself, the n-entry table (which only the single-kernel transform and the real <-> half-complex
+// steps read).
+int create_plan(dspmi_fft_t *plan, unsigned n, int precision, int device, bool c2c_only)
 {
     if (!plan || n == 0) return dspmi::fail(DSPMI_EINVAL, "fft_create: null plan pointer or n == 0");
     if (precision != DSPMI_F32 && precision != DSPMI_F64) return dspmi::fail(DSPMI_EINVAL, "fft_create: bad precision");
@@ -753,7 +760,7 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
             kM = dspmi::fft_find(M, precision);
             sub_M = !kM;
         }
-        if (n % 2 == 0 && n >= 4) {
+        if (n % 2 == 0 && n >= 4 && !c2c_only) {
             if (is_pow2(n / 2)) kh = dspmi::fft_find(n / 2, precision);
             sub_half = !kh;  // the n/2-point complex transform is a plan of its own (any-length or split)
         }
@@ -790,7 +797,7 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
         void *unused = nullptr;
         rc = noalloc_scratch(device, &unused);  // set-up time: the no-allocation entry point then only reads the table
     }
-    if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n, n, precision);
+    if (rc == DSPMI_OK && (k || !c2c_only)) rc = upload_twiddles(&pl->tw_n, n, precision);
     if (rc == DSPMI_OK && kh) rc = upload_twiddles(&pl->tw_half, n / 2, precision);
     if (rc == DSPMI_OK && k1) {
         // W_n^e = hi[e >> shift] * lo[e & mask]
@@ -806,9 +813,9 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
             rc = precision == DSPMI_F64 ? upload<double>(&pl->tw_lo, unit_circle<double>(1u << pl->tw_shift, n >> pl->tw_shift))
                                         : upload<float>(&pl->tw_lo, unit_circle<float>(1u << pl->tw_shift, n >> pl->tw_shift));
     }
-    if (rc == DSPMI_OK && sub_M) rc = dspmi_fft_create(&pl->plan_M, M, precision, device);
+    if (rc == DSPMI_OK && sub_M) rc = create_plan(&pl->plan_M, M, precision, device, true);
     if (rc == DSPMI_OK && M) rc = precision == DSPMI_F64 ? setup_bluestein<double>(pl) : setup_bluestein<float>(pl);
-    if (rc == DSPMI_OK && sub_half) rc = dspmi_fft_create(&pl->half_plan, n / 2, precision, device);
+    if (rc == DSPMI_OK && sub_half) rc = create_plan(&pl->half_plan, n / 2, precision, device, true);
     (void)hipSetDevice(prev);
     if (rc != DSPMI_OK) {
         dspmi_fft_destroy(pl);
@@ -816,6 +823,13 @@ int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
     }
     *plan = pl;
     return DSPMI_OK;
+}
+
+}  // namespace
+
+int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device)
+{
+    return create_plan(plan, n, precision, device, false);
 }
 
 int dspmi_fft_destroy(dspmi_fft_t plan)

@@ -998,7 +998,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
         const unsigned long long wait =
             blockIdx.x < extra ? 0 : (unsigned long long)a.stagger * (blockIdx.x - extra + (extra ? 1 : 0)) / (gridDim.x - extra);
         const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);  // bounded by the clock
+        // bounded by the clock, and by a count of sleeps in case the counter ticks at another rate
+        for (unsigned naps = 0; naps < 64 && __builtin_readcyclecounter() - t0 < wait; naps++) __builtin_amdgcn_s_sleep(32);
     }
     for (size_t frame = blockIdx.x; frame < total; frame += gridDim.x) {
         const size_t c = frame / a.npair;
