@@ -235,6 +235,16 @@ def compute_phi(z):
     return out
 
 
+def fftpy_power_spectrum(x):
+    """compute_power_spectrum of fftpy/main.py:30-45: |rfft(x, norm='ortho')| divided by its sum
+    over the n/2+1 bins (the 1/sqrt(n) of 'ortho' cancels), through this checker's own transform."""
+    mag = np.abs(fft_r2c(x))
+    q = 0.0
+    for m in mag:          # the reference's running sum, bin by bin
+        q += m
+    return mag / q
+
+
 def alsa_power_spectrum(z):
     """alsa/main.c:473-487 over the first len(z)//2 bins."""
     z, zp = _c2d(z)

@@ -406,3 +406,20 @@ def test_double_wrappers_on_long_windows(n):
     assert rel_l2(y, want_y) <= TOL_F64
     # properties that need no checker: the filter is linear and gain 1 everywhere returns the input
     assert rel_l2(dsp_amd.filter(x, np.ones(n // 2 + 1)), x) <= TOL_F64
+
+
+def test_fftpy_spectrum_vectors_from_numpy_rfft(golden_dir):
+    """fftpy/main.py:30-45 on the device: real transform of an odd or even window, magnitude, division
+    by the sum -- against vectors that numpy.fft.rfft itself produced (the reference's FFT for that
+    path; tests/golden/make_golden_fftpy.py).  f32 through the one-call spectrum op, double through
+    the drop-in r2c wrapper."""
+    g = np.load(os.path.join(golden_dir, "fftpy_spectrum.npz"))
+    for i in range(7):
+        x, want = g["x%d" % i], g["y%d" % i]
+        n = len(x)
+        plan = dsp_amd.FftPlan(n, "f32")
+        xd = torch.from_numpy(x.astype(np.float32)).cuda()[None, :].contiguous()
+        got32 = plan.r2c_spectrum(xd, nbin=n // 2 + 1, mode=dsp_amd.PS_NORM).cpu().numpy()[0]
+        assert rel_l2(got32, want) <= TOL_FFT, (i, n, rel_l2(got32, want))
+        mag = np.abs(dsp_amd.fft_r2c(x))
+        assert rel_l2(mag / mag.sum(), want) <= TOL_F64, (i, n)

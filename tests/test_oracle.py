@@ -162,3 +162,16 @@ def test_capture_block_stages_compose_from_their_parts():
     t.add(44100.0, 2000.0, 400.0, 0.0)
     raw = oracle.double_to_s16x2(t.read(5))
     assert raw.reshape(-1)[:6].tolist() == [400, 400, 383, 383, 336, 336]
+
+
+def test_fftpy_spectrum_against_numpy_rfft_vectors(golden_dir):
+    """The one FFT path of the reference whose FFT library is in this image: fftpy/main.py:30-45 calls
+    numpy.fft.rfft.  The vectors hold numpy's own output (tests/golden/make_golden_fftpy.py); the
+    checker's transform (long-double DFT off powers of two, radix-2 on them) must reproduce it."""
+    g = np.load(os.path.join(golden_dir, "fftpy_spectrum.npz"))
+    for i in range(7):
+        x, want = g["x%d" % i], g["y%d" % i]
+        got = oracle.fftpy_power_spectrum(x)
+        assert got.shape == want.shape == (len(x) // 2 + 1,)
+        assert np.linalg.norm(got - want) <= 1e-12 * np.linalg.norm(want), i
+        assert abs(got.sum() - 1.0) < 1e-12
