@@ -163,7 +163,8 @@ def fir_stream_f32(x, hist, h):
     return y
 
 
-# ---- DFT ("parity unpinned": FFTW is absent, see dsp_oracle.c) -------------
+# ---- DFT ("parity unpinned" for the C demos: FFTW is absent, see dsp_oracle.c; the fftpy
+# path, whose FFT is numpy.fft.rfft, is pinned by tests/golden/fftpy_spectrum.npz) -------------
 
 def _c2d(z):
     z = np.ascontiguousarray(z, dtype=np.complex128)
