@@ -256,7 +256,9 @@ __device__ __forceinline__ void fft_pass(C<T> *v, C<T> *lds, const C<T> *twr, co
 
 // Per-workgroup twiddle tables behind the FPB frame buffers: pass p holds W^{k*r},
 // r = 1..R-1, k < NS, as [r-1][k] so a wave reads contiguous entries.  Ends with a barrier.
-template <typename T, int N, int BT, int FPB, int R0, int R1, int R2, int R3>
+// TWS: the table `tw` holds exp(-2 pi i k / (TWS * N)): every TWS-th entry is read (a longer
+// transform's table serving its N-point rows).
+template <typename T, int N, int BT, int FPB, int R0, int R1, int R2, int R3, int TWS = 1>
 __device__ __forceinline__ void setup_lds_twiddles(char *smem_raw, const C<T> *__restrict__ tw, const C<T> *&tw1,
                                                    const C<T> *&tw2, const C<T> *&tw3)
 {
@@ -265,11 +267,11 @@ __device__ __forceinline__ void setup_lds_twiddles(char *smem_raw, const C<T> *_
     C<T> *t2 = t1 + (R1 > 1 ? (R1 - 1) * NS1 : 0);
     C<T> *t3 = t2 + (R2 > 1 ? (R2 - 1) * NS2 : 0);
     if constexpr (R1 > 1)
-        for (unsigned i = threadIdx.x; i < (R1 - 1) * NS1; i += BT) t1[i] = tw[(i % NS1) * (i / NS1 + 1) * (N / (NS1 * R1))];
+        for (unsigned i = threadIdx.x; i < (R1 - 1) * NS1; i += BT) t1[i] = tw[TWS * ((i % NS1) * (i / NS1 + 1) * (N / (NS1 * R1)))];
     if constexpr (R2 > 1)
-        for (unsigned i = threadIdx.x; i < (R2 - 1) * NS2; i += BT) t2[i] = tw[(i % NS2) * (i / NS2 + 1) * (N / (NS2 * R2))];
+        for (unsigned i = threadIdx.x; i < (R2 - 1) * NS2; i += BT) t2[i] = tw[TWS * ((i % NS2) * (i / NS2 + 1) * (N / (NS2 * R2)))];
     if constexpr (R3 > 1)
-        for (unsigned i = threadIdx.x; i < (R3 - 1) * NS3; i += BT) t3[i] = tw[(i % NS3) * (i / NS3 + 1) * (N / (NS3 * R3))];
+        for (unsigned i = threadIdx.x; i < (R3 - 1) * NS3; i += BT) t3[i] = tw[TWS * ((i % NS3) * (i / NS3 + 1) * (N / (NS3 * R3)))];
     __syncthreads();
     tw1 = t1;
     tw2 = t2;
@@ -1344,6 +1346,128 @@ const BluesteinEntry kBluesteinF32[] = {
 };
 
 // ---------------------------------------------------------------------------
+// c2c, 16384 points: radix-16 stage across the workgroup, one 1024-point row per wave
+// ---------------------------------------------------------------------------
+
+// The factorisation of ols_wave_kernel (n = n2 + 1024 n1, k = k1 + 16 k2) for the plain complex
+// transform: lane n2 loads x[n2 + 1024 n1], does the radix-16 sum and the W_N^(n2 k1) factors
+// (read from the plan's N-entry table, which also serves the rows' twiddles at stride 16), one
+// exchange hands wave k1 its row, the row's 1024-point transform runs inside the wave, and a
+// second exchange puts X[k1 + 16 k2] back into natural order for contiguous stores.  Two
+// workgroup-wide exchanges instead of three, and -- because a frame is only 16 points per lane --
+// the next frame is requested before the rows are transformed, so HBM works while the CU
+// computes (one 139 KB frame image fits a CU: without that, loading, computing and storing
+// would take turns).
+template <int NTMEM>
+__global__ __launch_bounds__(1024) void fft_c2c_rows_kernel(const C<float> *in, C<float> *out, const C<float> *__restrict__ tw,
+                                                            size_t batch, int flags)
+{
+    typedef float T;
+    constexpr int K1 = 16, NS = 1024, N = K1 * NS;
+    constexpr int R0 = 16, R1 = 4, R2 = 16;
+    constexpr int OROW = NS + 2;  // row pitch of the output image: lanes 16 rows apart hit different banks
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned tl = threadIdx.x, lane = tl & 63, wave = tl >> 6;
+    C<T> *img = reinterpret_cast<C<T> *>(smem_raw);
+    C<T> *wreg = img + (size_t)wave * padded_len(NS);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    setup_lds_twiddles<T, NS, 1024, K1, R0, R1, R2, 1, K1>(smem_raw, tw, tw1, tw2, tw3);
+    const bool backward = (flags & kFftBackward) != 0;  // swap . forward . swap
+
+    auto load_frame = [&](C<T> (&v)[K1], size_t f) {
+        const C<T> *src = in + f * N + tl;
+#pragma unroll
+        for (int n1 = 0; n1 < K1; n1++) {
+            const C<T> q = (NTMEM & 1) ? nt_load(src + NS * n1) : src[NS * n1];
+            v[n1] = backward ? C<T>{q.im, q.re} : q;
+        }
+    };
+
+    size_t f = blockIdx.x;
+    if (f >= batch) return;
+    C<T> v[K1];
+    load_frame(v, f);
+    for (; f < batch; f += gridDim.x) {
+        unsigned tt = tl;
+        asm volatile("" : "+v"(tt));  // the stage factors' addresses are the same for every frame
+        // stage factors W^(k1 n2) for k1 = 1, 2, 3 and 4, 8, 12; the others as two factors
+        C<T> lo[3], hi[3];
+#pragma unroll
+        for (int b = 1; b < 4; b++) lo[b - 1] = tw[tt * b];
+#pragma unroll
+        for (int a = 1; a < 4; a++) hi[a - 1] = tw[tt * 4 * a];
+        dft_reg<K1, 1>(v);
+#pragma unroll
+        for (int k1 = 1; k1 < K1; k1++) {
+            if (k1 / 4) v[k1] = cmul(v[k1], hi[k1 / 4 - 1]);
+            if (k1 % 4) v[k1] = cmul(v[k1], lo[k1 % 4 - 1]);
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = v[k1];
+        __syncthreads();
+        C<T> u[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) u[r] = img[NS * wave + lane + 64 * r];
+        __syncthreads();
+        // the next frame is on its way while this one's rows are transformed
+        const size_t fn = f + gridDim.x;
+        if (fn < batch) load_frame(v, fn);
+        unsigned la = lane;
+        asm volatile("" : "+v"(la));
+        run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u, wreg, tw1, tw2, tw3, tw, la);
+        __syncthreads();  // the waves' regions alias the image
+        C<T> *oimg = img + (size_t)OROW * wave + lane;
+#pragma unroll
+        for (int r = 0; r < 16; r++) oimg[64 * r] = u[r];  // X[wave + 16 k2] at [wave][k2], k2 = lane + 64 r
+        __syncthreads();
+        {
+            unsigned to = tl;
+            asm volatile("" : "+v"(to));
+            // natural order: k = to + 1024 j = k1 + 16 k2 with k1 = to % 16, k2 = to / 16 + 64 j
+            const C<T> *src = img + (size_t)OROW * (to & 15) + (to >> 4);
+            C<T> *dst = out + f * N + to;
+#pragma unroll
+            for (int j = 0; j < K1; j++) {
+                C<T> q = src[64 * j];
+                if (backward) q = C<T>{q.im, q.re};
+                if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + NS * j);
+                else dst[NS * j] = q;
+            }
+        }
+        __syncthreads();  // the image is free for the next frame's exchange
+    }
+}
+
+template <int NTMEM>
+int launch_c2c_rows(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
+{
+    constexpr int NS = 1024, K1 = 16;
+    constexpr size_t regions = (size_t)K1 * padded_len(NS) * sizeof(C<float>);
+    static_assert((size_t)K1 * (NS + 2) * sizeof(C<float>) <= regions, "the output image aliases the waves' regions");
+    constexpr size_t lds = regions + lds_twiddle_entries(2, 16, 4, 16, 1) * sizeof(C<float>);
+    auto kern = fft_c2c_rows_kernel<NTMEM>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    if (batch == 0) return DSPMI_OK;
+    size_t grid = batch < (size_t)num_cu ? batch : (size_t)num_cu;  // one workgroup fits a CU
+    {
+        const char *env = getenv("DSPMI_FFT_ITERS");  // experiment: frames per workgroup
+        if (env && atof(env) > 0) {
+            const size_t g = (size_t)((double)batch / atof(env) + 0.999);
+            if (g > grid) grid = g > batch ? batch : g;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, static_cast<const C<float> *>(in), static_cast<C<float> *>(out),
+                       static_cast<const C<float> *>(tw), batch, backward ? kFftBackward : 0);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+// ---------------------------------------------------------------------------
 // launchers and the kernel table
 // ---------------------------------------------------------------------------
 
@@ -1491,9 +1615,11 @@ const FftEntry kF32[] = {
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
     F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),    F32T(4096, 256, 16, 16, 16, 1, 2),
     F32T(8192, 512, 16, 16, 16, 2, 3),
-    {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 0>, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 3>,
-     "fft_f32_n16384_r16x16x16x4_splittw", nullptr, nullptr},
+    {16384, launch_c2c_rows<0>, launch_c2c_rows<3>, "fft_f32_n16384_r16_rows1024", nullptr, nullptr},
 };
+// the 16384-point transform as one frame image exchanged three times (A/B: DSPMI_FFT_VARIANT=1 at N = 16384)
+const FftEntry kF32Alt16384 = {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 0>,
+                               launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 3>, "fft_f32_n16384_r16x16x16x4_splittw", nullptr, nullptr};
 const FftEntry kF64[] = {
     F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),
     F64(16, 2, 8, 2, 1, 1),       F64(32, 4, 8, 4, 1, 1),        F64(64, 8, 8, 8, 1, 1),
@@ -1517,6 +1643,10 @@ const FftEntry *find_entry(unsigned n, int precision)
     if (n == 1024 && precision == DSPMI_F32) {
         const char *env = getenv("DSPMI_FFT_VARIANT");
         if (env && atoi(env) >= 1 && atoi(env) <= 5) return &kF32Alt1024[atoi(env) - 1];
+    }
+    if (n == 16384 && precision == DSPMI_F32) {
+        const char *env = getenv("DSPMI_FFT_VARIANT");
+        if (env && atoi(env) == 1) return &kF32Alt16384;
     }
     const FftEntry *tab = precision == DSPMI_F64 ? kF64 : kF32;
     const size_t cnt = precision == DSPMI_F64 ? sizeof(kF64) / sizeof(kF64[0]) : sizeof(kF32) / sizeof(kF32[0]);
