@@ -1439,6 +1439,123 @@ __global__ __launch_bounds__(1024) void fft_c2c_rows_kernel(const C<float> *in, 
     }
 }
 
+// The same for 32768 points: 32 points per lane (no room to request the next frame early), two
+// rows per wave, and -- the frame being 256 KB -- both exchanges move the real parts, then the
+// imaginary parts, through a 32768-float image, as in ols_wave_kernel.
+template <int NTMEM>
+__global__ __launch_bounds__(1024) void fft_c2c_rows32_kernel(const C<float> *in, C<float> *out, const C<float> *__restrict__ tw,
+                                                              size_t batch, int flags)
+{
+    typedef float T;
+    constexpr int K1 = 32, NS = 1024, N = K1 * NS, SPW = 2;
+    constexpr int R0 = 16, R1 = 4, R2 = 16;
+    constexpr int OROW = NS + 1;  // row pitch of the output image (floats): 32 rows read at once fall on 32 banks
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned tl = threadIdx.x, lane = tl & 63, wave = tl >> 6;
+    float *img = reinterpret_cast<float *>(smem_raw);
+    C<T> *wreg = reinterpret_cast<C<T> *>(smem_raw) + (size_t)wave * padded_len(NS);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    setup_lds_twiddles<T, NS, 1024, 16, R0, R1, R2, 1, K1>(smem_raw, tw, tw1, tw2, tw3);
+    const bool backward = (flags & kFftBackward) != 0;  // swap . forward . swap
+
+    for (size_t f = blockIdx.x; f < batch; f += gridDim.x) {
+        unsigned tt = tl;
+        asm volatile("" : "+v"(tt));
+        C<T> v[K1];
+        {
+            const C<T> *src = in + f * N + tt;
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                const C<T> q = (NTMEM & 1) ? nt_load(src + NS * n1) : src[NS * n1];
+                v[n1] = backward ? C<T>{q.im, q.re} : q;
+            }
+        }
+        // stage factors W^(k1 n2) for k1 = 1, 2, 3 and 4, 8, .. 28; the others as two factors
+        C<T> lo[3], hi[7];
+#pragma unroll
+        for (int b = 1; b < 4; b++) lo[b - 1] = tw[tt * b];
+#pragma unroll
+        for (int a = 1; a < 8; a++) hi[a - 1] = tw[tt * 4 * a];
+        dft_reg<K1, 1>(v);
+#pragma unroll
+        for (int k1 = 1; k1 < K1; k1++) {
+            if (k1 / 4) v[k1] = cmul(v[k1], hi[k1 / 4 - 1]);
+            if (k1 % 4) v[k1] = cmul(v[k1], lo[k1 % 4 - 1]);
+        }
+        C<T> u[SPW][16];
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+#pragma unroll
+            for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = comp ? v[k1].im : v[k1].re;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < SPW; s++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float q = img[NS * (wave * SPW + s) + lane + 64 * r];
+                    if (comp) u[s][r].im = q;
+                    else u[s][r].re = q;
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < SPW; s++) {
+            unsigned la = lane;
+            asm volatile("" : "+v"(la));
+            run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw, la);
+        }
+        __syncthreads();  // the waves' regions alias the image
+        unsigned to = tl;
+        asm volatile("" : "+v"(to));
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            // X[k1 + 32 k2] of row k1 at [k1][k2]
+#pragma unroll
+            for (int s = 0; s < SPW; s++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) img[OROW * (wave * SPW + s) + lane + 64 * r] = comp ? u[s][r].im : u[s][r].re;
+            __syncthreads();
+            // natural order: k = to + 1024 j = k1 + 32 k2 with k1 = to % 32, k2 = to / 32 + 32 j
+            const float *src = img + OROW * (to & 31) + (to >> 5);
+#pragma unroll
+            for (int j = 0; j < K1; j++) {
+                if (comp) v[j].im = src[32 * j];
+                else v[j].re = src[32 * j];
+            }
+            __syncthreads();
+        }
+        C<T> *dst = out + f * N + to;
+#pragma unroll
+        for (int j = 0; j < K1; j++) {
+            const C<T> q = backward ? C<T>{v[j].im, v[j].re} : v[j];
+            if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + NS * j);
+            else dst[NS * j] = q;
+        }
+    }
+}
+
+template <int NTMEM>
+int launch_c2c_rows32(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
+{
+    constexpr int NS = 1024, K1 = 32;
+    constexpr size_t regions = (size_t)16 * padded_len(NS) * sizeof(C<float>);
+    static_assert((size_t)K1 * (NS + 1) * sizeof(float) <= regions, "the images alias the waves' regions");
+    constexpr size_t lds = regions + lds_twiddle_entries(2, 16, 4, 16, 1) * sizeof(C<float>);
+    auto kern = fft_c2c_rows32_kernel<NTMEM>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    if (batch == 0) return DSPMI_OK;
+    const size_t grid = batch < (size_t)num_cu ? batch : (size_t)num_cu;  // one workgroup fits a CU
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, static_cast<const C<float> *>(in), static_cast<C<float> *>(out),
+                       static_cast<const C<float> *>(tw), batch, backward ? kFftBackward : 0);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
 template <int NTMEM>
 int launch_c2c_rows(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
 {
@@ -1616,6 +1733,7 @@ const FftEntry kF32[] = {
     F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),    F32T(4096, 256, 16, 16, 16, 1, 2),
     F32T(8192, 512, 16, 16, 16, 2, 3),
     {16384, launch_c2c_rows<0>, launch_c2c_rows<3>, "fft_f32_n16384_r16_rows1024", nullptr, nullptr},
+    {32768, launch_c2c_rows32<0>, launch_c2c_rows32<3>, "fft_f32_n32768_r32_rows1024", nullptr, nullptr},
 };
 // the 16384-point transform as one frame image exchanged three times (A/B: DSPMI_FFT_VARIANT=1 at N = 16384)
 const FftEntry kF32Alt16384 = {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 0>,

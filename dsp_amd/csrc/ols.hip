@@ -176,7 +176,7 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     // points (fft_stockham.hip, ols_wave_kernel).  Its tables: exp(-2 pi i k / 1024), k < 1024,
     // followed by the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]; H is stored row by row,
     // H[k1 + rows * k2] at [k1][k2].
-    const unsigned rows = N > 16384 ? N / 1024 : 0;
+    const unsigned rows = (N > 16384 && !composed) ? N / 1024 : 0;  // the five-kernel composition keeps the plain layout
     const long double two_pi = 6.283185307179586476925286766559005768L;
     std::vector<C32> tw(rows ? 1024 + (size_t)N : N), h(N, C32{0.f, 0.f});
     if (rows) {

@@ -148,7 +148,7 @@ typedef struct dspmi_fft_plan *dspmi_fft_t;
 
 /* n: transform length (complex points, or real samples for r2c/c2r): any length up to 2^24
  * points, 2^22 when it is not a power of two (the reference's tools transform whatever window
- * their input holds, util/fft/fft.c:321-352); DSPMI_ENOSYS beyond.  Powers of two up to 16384
+ * their input holds, util/fft/fft.c:321-352); DSPMI_ENOSYS beyond.  Powers of two up to 32768
  * (f32) / 8192 (f64) run as one kernel, longer ones as two batched passes of those kernels
  * (n = n1 * n2), other lengths through a chirp-z convolution of a power-of-two length. */
 int dspmi_fft_create(dspmi_fft_t *plan, unsigned n, int precision, int device);
