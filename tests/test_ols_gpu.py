@@ -123,3 +123,22 @@ def test_fir_plan_takes_the_long_block_path_with_history(nh):
     want = oracle.fir_batch_f32(x, h, 2 * chunk)
     for c in range(nchan):
         check_blocks(got[c], want[c], x[c], h, (nh, c))
+
+
+@pytest.mark.parametrize("nh,fft_n", [(127, 1024), (1000, 4096), (8191, 16384), (8191, 32768)])
+def test_fused_kernels_agree_with_the_five_kernel_composition(nh, fft_n, monkeypatch):
+    """DSPMI_OLS_COMPOSED=1 runs the same arithmetic as five kernels through HBM (gather, batched
+    transform, multiply, batched transform, scatter): the A/B reference of the one-kernel forms."""
+    rng = np.random.default_rng(nh + fft_n)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (2, 3 * fft_n + 777)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    fused = dsp_amd.OlsPlan(h, fft_n)
+    monkeypatch.setenv("DSPMI_OLS_COMPOSED", "1")
+    composed = dsp_amd.OlsPlan(h, fft_n)
+    monkeypatch.delenv("DSPMI_OLS_COMPOSED")
+    a, b = fused.exec(xd).cpu().numpy(), composed.exec(xd).cpu().numpy()
+    want = oracle.fir_batch_f32(x, h, x.shape[1])
+    for c in range(2):
+        check_blocks(a[c], want[c], x[c], h, ("fused", nh, fft_n, c))
+        check_blocks(b[c], want[c], x[c], h, ("composed", nh, fft_n, c))
