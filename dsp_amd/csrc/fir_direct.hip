@@ -26,6 +26,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -490,6 +491,264 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// f32 FIR on the bf16 matrix pipe: operands split three ways
+// ---------------------------------------------------------------------------
+//
+// A float is the exact sum of three bf16 values (8 significant bits each: hi = the float rounded
+// to bf16, mid = the remainder rounded, lo = what is left).  With samples and taps both split,
+// a product is the sum of nine bf16 products, of which the six largest are kept:
+//   hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi       (the dropped ones are below 2^-24 of it)
+// each exact in the f32 accumulator of v_mfma_f32_16x16x32_bf16.  That instruction retires
+// sixteen times the products per cycle of the f32 one, so six of them per 32 window positions
+// cost 3/8 of the f32 MFMA chain over the same window.
+//
+// The tap matrix is the A operand (row b = output within its block of 16, k = window position
+// m, entry h[P + b - m]) and stays in registers; the B operand's column a is the window of
+// block a, read from LDS as eight consecutive bf16 samples per lane and plane: one 16-byte
+// read, conflict-free on unpadded planes (lane groups of that read land on distinct 16-byte
+// slots for a 32-byte lane stride).  NS = 32-position slices of the window: NS*32 >= nh + 15.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kSplitTile = 4096;  // outputs per workgroup step: 4 waves x 4 blocks of 256
+constexpr int kSplitMaxSlices = 10;
+constexpr size_t split_lds_bytes(int ns) { return (size_t)2 * 3 * (kSplitTile + 32 * ns - 16) * 2; }  // two sets of three planes
+
+// bf16(lo) in the low half, bf16(hi) in the high half, both rounded to nearest even
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// two floats -> their three bf16 parts, packed pairwise; every subtraction is exact
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo)
+{
+    hi = cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = cvt_pk_bf16(r0, r1);
+    r0 -= __builtin_bit_cast(float, mid << 16);
+    r1 -= __builtin_bit_cast(float, mid & 0xffff0000u);
+    lo = cvt_pk_bf16(r0, r1);
+}
+
+// A workgroup walks consecutive tiles of 4096 outputs.  The three planes are double-buffered:
+// while the MFMAs of tile i read one set, the same waves split tile i+1 (whose samples arrived
+// in registers during tile i-1) into the other set, piece by piece between the MFMA steps, and
+// reissue each register's load for tile i+2 as soon as it is free.  Loads are therefore in
+// flight for a whole tile time, the split's vector instructions sit in the issue slots the
+// 16-cycle MFMAs leave open, and a tile costs one barrier.
+//
+// Every tile issues the same memory instructions, none under a branch: samples come through a
+// buffer descriptor over the part of the row the window covers (a 16-byte access is range-checked
+// dword by dword, so whatever lies outside the row reads as zero), the caller's history
+// through a second descriptor that is empty except for a row's first tile, results leave through
+// a third.  With a fixed count per tile the compiler's wait for a staging register can leave all
+// younger operations outstanding; one conditional load or store in the loop and it waits for
+// nearly everything, the loads issued moments before included.
+template <int NS>
+__global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab)
+{
+    constexpr int P = 32 * NS - 16;          // window positions ahead of a block's first output
+    constexpr int NSTAGE = kSplitTile + P;   // samples staged per tile (a multiple of 16)
+    constexpr int NQ = NSTAGE / 4;           // ... in groups of four
+    constexpr int NIT = (NQ + 255) / 256;    // groups per lane (the last one on a few lanes only)
+    constexpr int NSTEP = 4 * NS;            // MFMA steps per wave and tile
+    static_assert(P / 4 <= 256, "the history falls into every lane's first group");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned short *lds = reinterpret_cast<unsigned short *>(smem_raw);  // [2][3][NSTAGE]
+
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63, wave = t >> 6;
+    const long nx = p.nx, nh = p.nh;
+
+    bf16x8 hf[NS][3];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) hf[s][pl] = __builtin_bit_cast(bf16x8, htab[(s * 3 + pl) * 64 + lane]);
+
+    const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
+    const long tile_hi = min(tile_lo + (long)p.tiles_per_block, (long)p.ntiles_total);
+    if (tile_hi <= tile_lo) return;
+    const long nunits = tile_hi - tile_lo;
+    unsigned cur_chan = (unsigned)(tile_lo / p.tiles_per_chan);
+    unsigned cur_tile = (unsigned)(tile_lo - (long)cur_chan * p.tiles_per_chan);
+
+    // a descriptor must be provably wave-uniform, or every access through it is wrapped in a
+    // serialising loop: rebuild the pointer from scalar halves
+    auto descriptor = [](const void *ptr, int bytes) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+        // (the builtin returns int: without the unsigned casts the low half would sign-extend over the high one)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        void *base = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(base, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+
+    struct Unit {
+        const float *xbase, *hbase;  // first sample / first history sample the descriptors cover
+        int xbytes, hbytes;          // ... and how much (0: nothing to read)
+        int xoff, hoff;              // byte offset of the window's first sample from those
+        long tile_start;
+        unsigned chan;
+    };
+    long described = 0;
+    auto describe = [&]() {
+        Unit d;
+        const bool valid = described++ < nunits;  // a tile past this workgroup's last reads nothing
+        d.chan = valid ? cur_chan : 0;
+        d.tile_start = (long)cur_tile * kSplitTile;
+        if (++cur_tile == p.tiles_per_chan) {
+            cur_tile = 0;
+            ++cur_chan;
+        }
+        const long sbase = d.tile_start - P;          // the window is samples [sbase, sbase + NSTAGE)
+        const long lo = sbase < 0 ? 0 : sbase;
+        long n = min(nx, sbase + NSTAGE) - lo;
+        if (n < 0 || !valid) n = 0;
+        d.xbase = p.x + (size_t)d.chan * p.x_stride + lo;
+        d.xbytes = (int)n * 4;
+        d.xoff = (int)(sbase - lo) * 4;               // <= 0: an offset before the row is out of range
+        // history sample j stands for sample j - (nh - 1) of the row
+        const bool hist = valid && p.hist && sbase < 0;
+        d.hbase = hist ? p.hist + (size_t)d.chan * p.hist_stride : p.x;
+        d.hbytes = hist ? (int)(nh - 1) * 4 : 0;
+        d.hoff = (int)(sbase + nh - 1) * 4;
+        return d;
+    };
+
+    f32x4 stage[NIT];
+    u32x4 hstage;  // the history's share of the first group (zero except in a row's first tile)
+    auto load_piece = [&](const Unit &d, int it) {
+        // lanes past the window's end repeat its last group (and drop it in put_piece)
+        const unsigned u = t + 256 * it;
+        const int g = (int)(it < NIT - 1 || u < (unsigned)NQ ? u : (unsigned)NQ - 1) * 16;
+        // Offsets before the row: the offset is unsigned to the hardware, so they go to one that is
+        // out of range for every length.  A group of samples starts a multiple of four samples from
+        // the row's start, so it lies before the row entirely or not at all; the history does not
+        // line up with the groups and is read sample by sample.
+        const int xo = d.xoff + g;
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(descriptor(d.xbase, d.xbytes), xo < 0 ? 0x7ffffff0 : xo, 0, 0));
+        if (it == 0) {
+            const __amdgpu_buffer_rsrc_t hrsrc = descriptor(d.hbase, d.hbytes);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ho = d.hoff + g + 4 * e;
+                hstage[e] = __builtin_amdgcn_raw_buffer_load_b32(hrsrc, ho < 0 ? 0x7ffffff0 : ho, 0, 0);
+            }
+        }
+    };
+    auto put_piece = [&](unsigned short *planes, int it) {
+        const unsigned u = t + 256 * it;
+        f32x4 v = stage[it];
+        if (it == 0) v = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, v) | hstage);
+        if (it < NIT - 1 || u < (unsigned)NQ) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split_pair(v[0], v[1], h0, m0, l0);
+            split_pair(v[2], v[3], h1, m1, l1);
+            *reinterpret_cast<u32x2 *>(planes + 4 * u) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2 *>(planes + NSTAGE + 4 * u) = (u32x2){m0, m1};
+            *reinterpret_cast<u32x2 *>(planes + 2 * NSTAGE + 4 * u) = (u32x2){l0, l1};
+        }
+    };
+
+    // B operand: lane holds column a = lane&15 (block a of 16 outputs), window positions
+    // 8*(lane>>4) .. +7 of each slice
+    const unsigned b_base = wave * 1024 + 16 * (lane & 15) + 8 * (lane >> 4);
+
+    Unit cur = describe();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) load_piece(cur, it);
+    // The tap images must have landed before the loop: left pending, the compiler's wait for
+    // them inside the loop would also wait for each iteration's prefetch (the counter is in order).
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) asm volatile("" : "+v"(hf[s][pl]));
+#pragma unroll
+    for (int it = 0; it < NIT; it++) put_piece(lds, it);
+    Unit nxt = describe();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) load_piece(nxt, it);
+    __syncthreads();
+
+    // One tile: its MFMAs out of one set of planes and, step by step, the next tile's split into
+    // the other set and the loads of the tile after it.  A step = one slice of one block of 256
+    // outputs: three 16-byte reads, six MFMAs (96 cycles); reads run two steps ahead of the MFMAs
+    // that use them.  The leading products go to one accumulator and the five corrections to
+    // another: the small terms then round against each other, not against the running sum.
+    auto iteration = [&](long unit) {
+        const unsigned short *rd_planes = lds + (unit & 1) * (3 * NSTAGE);
+        unsigned short *wr_planes = lds + ((unit & 1) ^ 1) * (3 * NSTAGE);
+        const Unit nxt2 = describe();
+        // results leave through a descriptor over this tile's part of the row: the row's ragged
+        // end needs no branch, and only 4-byte alignment
+        const long left = (long)p.nxx - cur.tile_start;
+        const __amdgpu_buffer_rsrc_t yrsrc = descriptor(p.y + (size_t)cur.chan * p.y_stride + cur.tile_start,
+                                                        (int)(left < kSplitTile ? left : kSplitTile) * 4);
+        bf16x8 xf[3][3];
+        f32x4 big[4], small[4];
+        const unsigned short *xp = rd_planes + b_base;
+        auto rd = [&](int step) {
+            const int off = 256 * (step / NS) + 32 * (step % NS);
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+                xf[step % 3][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(xp + pl * NSTAGE + off));
+        };
+        auto store = [&](int q) {
+            // D layout: column a = lane&15, rows 4*(lane>>4) .. +3 -> four consecutive outputs per
+            // lane, the wave's 64 lanes cover 1 KiB contiguously
+            u32x4 res;
+#pragma unroll
+            for (int r = 0; r < 4; r++) res[r] = __builtin_bit_cast(unsigned, big[q][r] + small[q][r]);
+            const int off = (int)(wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(res, yrsrc, off, 0, 2);  // nontemporal
+        };
+        rd(0);
+        if (NSTEP > 1) rd(1);
+        int piece = 0;
+#pragma unroll
+        for (int step = 0; step < NSTEP; step++) {
+            const int q = step / NS, s = step % NS, slot = step % 3;
+            if (step + 2 < NSTEP) rd(step + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sm = s ? small[q] : zero, bg = s ? big[q] : zero;
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[s][0], xf[slot][2], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[s][2], xf[slot][0], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[s][1], xf[slot][1], sm, 0, 0, 0);
+            bg = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[s][0], xf[slot][0], bg, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[s][0], xf[slot][1], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[s][1], xf[slot][0], sm, 0, 0, 0);
+            small[q] = sm;
+            big[q] = bg;
+#pragma unroll
+            for (; piece < NIT && piece * NSTEP < (step + 1) * NIT; piece++) {
+                put_piece(wr_planes, piece);
+                load_piece(nxt2, piece);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // a block's results leave one step after its last MFMA, when the pipe has drained
+            if (s == 0 && q > 0) store(q - 1);
+        }
+        store(3);
+        if (unit + 1 < nunits) __syncthreads();  // the other planes are complete, and every wave has left these
+        cur = nxt;
+        nxt = nxt2;
+    };
+    // The first tile runs from a copy of the loop body.  Where two paths meet, the compiler keeps
+    // the smaller count of operations that may stay outstanding: entering the loop straight from
+    // the prologue (its loads back to back) would make every iteration wait as if it were the first.
+    iteration(0);
+    for (long unit = 1; unit < nunits; unit++) iteration(unit);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -507,6 +766,10 @@ struct dspmi_fir_plan {
     // FFTs cost fewer flops than 2*nh per sample and run faster from about 64 taps (doc/notes:81-82)
     dspmi_ols_t ols = nullptr;
     unsigned ols_n = 0;
+    // f32 plans of up to 32 * kSplitMaxSlices - 15 taps: the tap matrix of the bf16 kernel, as
+    // [slice][part][lane] register images, and its slice count
+    void *split_tab = nullptr;
+    int split_ns = 0;
     char name[48] = "";
 };
 
@@ -574,7 +837,104 @@ int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
     return launch_mfma_t<4>(p, nchan, 8, stream);
 }
 
+// float -> bf16, round to nearest even (finite inputs)
+inline unsigned short to_bf16(float v)
+{
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline float from_bf16(unsigned short b)
+{
+    const unsigned u = (unsigned)b << 16;
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+
+// The A-operand images of fir_split_kernel: lane (b = lane & 15, g = lane >> 4) of slice s holds
+// tap-matrix entries [b][32 s + 8 g + j], j = 0..7, entry [b][m] = h[P + b - m] (0 outside the taps).
+std::vector<unsigned short> split_tap_images(const float *taps, unsigned nh, int ns)
+{
+    const int P = 32 * ns - 16;
+    std::vector<unsigned short> part[3];
+    for (auto &v : part) v.assign(nh, 0);
+    for (unsigned k = 0; k < nh; k++) {
+        float r = taps[k];
+        for (int pl = 0; pl < 3; pl++) {
+            part[pl][k] = to_bf16(r);
+            r -= from_bf16(part[pl][k]);
+        }
+    }
+    std::vector<unsigned short> img((size_t)ns * 3 * 64 * 8, 0);
+    for (int s = 0; s < ns; s++)
+        for (int pl = 0; pl < 3; pl++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int m = 32 * s + 8 * (lane >> 4) + j, k = P + (lane & 15) - m;
+                    if (k >= 0 && k < (int)nh) img[(((size_t)s * 3 + pl) * 64 + lane) * 8 + j] = part[pl][k];
+                }
+    return img;
+}
+
+template <int NS>
+int launch_split_t(const FirParams<float> &p, const void *tab, unsigned blocks, hipStream_t stream)
+{
+    size_t lds = split_lds_bytes(NS);
+    {
+        const char *env = getenv("DSPMI_FIR_BPC");  // experiments: cap the resident workgroups per CU
+        if (env && atoi(env) > 0) {
+            const size_t want = (160 * 1024) / atoi(env) - 512;
+            if (want > lds) lds = want;
+        }
+    }
+    auto kern = fir_split_kernel<NS>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, p, static_cast<const u32x4 *>(tab));
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int launch_split(FirParams<float> p, const void *tab, int ns, unsigned nchan, hipStream_t stream)
+{
+    p.tiles_per_chan = (unsigned)(((unsigned long long)p.nxx + kSplitTile - 1) / kSplitTile);
+    const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
+    if (tiles == 0) return DSPMI_OK;
+    if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
+    p.ntiles_total = (unsigned)tiles;
+    // every workgroup loads the tap images once (12 registers per slice) and then walks its tiles
+    unsigned tpb = (unsigned)(tiles / 8192);
+    p.tiles_per_block = tpb < 2 ? (tiles >= 2048 ? 2 : 1) : (tpb > 16 ? 16 : tpb);
+    {
+        const char *env = getenv("DSPMI_FIR_TPB");  // experiment knob
+        if (env && atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
+    }
+    const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
+    switch (ns) {
+    case 1: return launch_split_t<1>(p, tab, blocks, stream);
+    case 2: return launch_split_t<2>(p, tab, blocks, stream);
+    case 3: return launch_split_t<3>(p, tab, blocks, stream);
+    case 4: return launch_split_t<4>(p, tab, blocks, stream);
+    case 5: return launch_split_t<5>(p, tab, blocks, stream);
+    case 6: return launch_split_t<6>(p, tab, blocks, stream);
+    case 7: return launch_split_t<7>(p, tab, blocks, stream);
+    case 8: return launch_split_t<8>(p, tab, blocks, stream);
+    case 9: return launch_split_t<9>(p, tab, blocks, stream);
+    case 10: return launch_split_t<10>(p, tab, blocks, stream);
+    }
+    return dspmi::fail(DSPMI_EINVAL, "fir: no bf16 kernel of %d slices", ns);
+}
+
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
+// Tap counts the bf16 kernel takes by default (measured, 512 x 2^20 samples: 63 taps 0.80 ms against
+// 0.93 for the f32 matrix kernel; 127 taps 0.95-0.98 against 1.03 for overlap-save; from about 150
+// taps overlap-save wins, below 33 the f32 kernel is as fast).
+constexpr unsigned kSplitAutoMinTaps = 33, kSplitAutoMaxTaps = 145;
 constexpr unsigned kOlsMinTaps = 64;  // measured crossover (direct 1.12 ms vs 1.08 at 64 taps; direct wins below)
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
@@ -626,12 +986,29 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
     if (precision == DSPMI_F64) {
         pl->variant = V_F64_EXACT;
     } else {
-        // A/B knob: "valu" or "mfma" pins that direct kernel; any other value means automatic
+        // A/B knob: "valu", "mfma" (the f32 matrix kernel), "bf16" (the split kernel wherever it
+        // applies) or "ols" (overlap-save from kOlsMinTaps up) pin that path; anything else is automatic
         const char *env = getenv("DSPMI_FIR_VARIANT");
-        const bool valu = env && !strcmp(env, "valu"), pinned = valu || (env && !strcmp(env, "mfma"));
+        const bool valu = env && !strcmp(env, "valu"), mfma = env && !strcmp(env, "mfma");
+        const bool want_split = env && !strcmp(env, "bf16"), want_ols = env && !strcmp(env, "ols");
         pl->variant = valu ? (nh <= 32 ? V_F32_SHORT : V_F32_LONG) : V_F32_MFMA;
         if constexpr (sizeof(T) == 4) {
-            if (!pinned && nh >= kOlsMinTaps && nh <= 8192) {
+            const unsigned split_max = want_split ? 32 * kSplitMaxSlices - 15 : kSplitAutoMaxTaps;
+            if (!valu && !mfma && !want_ols && nh >= kSplitAutoMinTaps && nh <= split_max) {
+                pl->split_ns = (int)((nh + 15 + 31) / 32);
+                const std::vector<unsigned short> img = split_tap_images(taps, nh, pl->split_ns);
+                e = hipSetDevice(device);
+                if (e == hipSuccess) e = hipMalloc(&pl->split_tab, img.size() * 2);
+                if (e == hipSuccess) e = hipMemcpy(pl->split_tab, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+                (void)hipSetDevice(prev);
+                if (e != hipSuccess) {
+                    (void)hipFree(pl->split_tab);
+                    (void)hipFree(pl->taps_dev);
+                    delete pl;
+                    return dspmi::fail(DSPMI_EIO, "fir_create: %s", hipGetErrorString(e));
+                }
+            }
+            if (!valu && !mfma && !pl->split_tab && nh >= kOlsMinTaps && nh <= 8192) {
                 // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
                 // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384; beyond 2048
                 // taps the plan's own default (32768-point blocks)
@@ -643,7 +1020,8 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
             }
         }
     }
-    if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
+    if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
+    else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
     else snprintf(pl->name, sizeof pl->name, "%s", kVariantName[pl->variant]);
     *out = pl;
     return DSPMI_OK;
@@ -672,6 +1050,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
         if (pl->ols && flags == 0 && nxx == nx && nx >= 2 * pl->ols_n)
             return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+        if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
             return launch_mfma(p, nchan, s);
         }
@@ -715,6 +1094,7 @@ int dspmi_fir_destroy(dspmi_fir_t plan)
 {
     if (!plan) return DSPMI_OK;
     if (plan->ols) (void)dspmi_ols_destroy(plan->ols);
+    (void)hipFree(plan->split_tab);
     hipError_t e = hipFree(plan->taps_dev);
     delete plan;
     if (e != hipSuccess) return dspmi::fail(DSPMI_EIO, "fir_destroy: %s", hipGetErrorString(e));

@@ -82,10 +82,12 @@ def test_wrapper_long_kernel_multi_segment():
 
 # ---- f32 device API -----------------------------------------------------------------
 
-@pytest.fixture(params=["auto", "mfma"])
+@pytest.fixture(params=["auto", "mfma", "ols"])
 def fir_path(request, monkeypatch):
-    """Plans pick overlap-save for long filters on long rows; "mfma" pins the direct kernel so
-    both are checked on the same cases."""
+    """A plan picks its kernel by tap count (the f32 matrix kernel for the shortest filters, the
+    bf16 split kernel in the middle, overlap-save for long filters on long rows); "mfma" pins
+    the f32 matrix kernel and "ols" overlap-save from 64 taps up, so all three are checked on
+    the same cases."""
     if request.param != "auto":
         monkeypatch.setenv("DSPMI_FIR_VARIANT", request.param)
     return request.param
@@ -224,7 +226,8 @@ def test_linearity_and_impulse_at_scale(fir_path):
     nh, nchan, nx = 127, 64, 1 << 20
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     plan = dsp_amd.FirPlan(h, "f32")
-    assert ("overlap_save" in plan.variant) == (fir_path == "auto")
+    assert ("overlap_save" in plan.variant) == (fir_path == "ols")
+    assert ("bf16" in plan.variant) == (fir_path == "auto")
     g = torch.Generator(device="cuda").manual_seed(1)
     a = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
     b = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
@@ -235,8 +238,9 @@ def test_linearity_and_impulse_at_scale(fir_path):
     imp[0, 0] = 1.0
     imp[1, nx - 200] = 1.0
     yi = plan.exec(imp).cpu().numpy()
-    if fir_path == "mfma":
-        # one product per output, added to zeros: the taps come back exactly
+    if fir_path != "ols":
+        # one product per output, added to zeros: the taps come back exactly (in the split kernel
+        # the sample 1.0 is its own leading part, and a tap's three parts add up to it exactly)
         assert np.array_equal(yi[0, :nh], h) and not yi[0, nh:].any()
         assert np.array_equal(yi[1, nx - 200:nx - 200 + nh], h) and not yi[1, :nx - 200].any()
     else:
@@ -320,3 +324,106 @@ def test_in_place_is_refused_interleaved_rows_are_not(fir_path):
     y = plan.exec(x, y=buf[:, nx:2 * nx])
     for c in range(nchan):
         assert rel_l2(y[c].cpu().numpy(), want[c, :nx]) <= TOL_FIR
+
+
+# ---- the bf16 split kernel (17..305 taps) ---------------------------------------------
+
+def split_plan(h, monkeypatch):
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", "bf16")
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert "bf16" in plan.variant, plan.variant
+    return plan
+
+
+@pytest.mark.parametrize("nh", [17, 18, 48, 49, 100, 127, 177, 178, 256, 305])
+def test_split_kernel_every_slice_count(nh, monkeypatch):
+    """One tap count at and one past the edges of the 32-position slices (nh + 15 = 32 k), ragged
+    rows of every length class: shorter than a tile, a tile plus a few, rows that end inside a
+    16-byte group; outputs cut at nx and run on to nx + nh."""
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = split_plan(h, monkeypatch)
+    rng = np.random.default_rng(nh)
+    for nx, nchan in [(3, 2), (nh - 1, 1), (4095, 3), (4097, 2), (9001, 3), (3 * 4096 + 2, 2)]:
+        x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        for nxx in (nx, nx + nh, nx + nh - 1, max(1, nx - 5)):
+            got = plan.exec(xd, nxx).cpu().numpy()
+            want = oracle.fir_batch_f32(x, h, nxx)
+            for c in range(nchan):
+                assert max(block_errors(got[c], want[c])) <= TOL_FIR, (nh, nx, nxx, c)
+
+
+@pytest.mark.parametrize("nh,chunk", [(127, 8192), (100, 5000), (33, 4096), (305, 4097), (64, 300)])
+def test_split_kernel_streaming_history(nh, chunk, monkeypatch):
+    """A row cut in chunks with the previous chunk's tail as history gives the row's outputs; tap
+    counts whose history does not line up with the 16-byte groups of the window, chunks shorter
+    than the history included."""
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = split_plan(h, monkeypatch)
+    rng = np.random.default_rng(nh + chunk)
+    nchan, nchunk = 3, 4
+    x = rng.uniform(-1, 1, (nchan, nchunk * chunk)).astype(np.float32)
+    whole = oracle.fir_batch_f32(x, h, x.shape[1])
+    xd = torch.from_numpy(x).cuda()
+    hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
+    outs = []
+    for k in range(nchunk):
+        piece = xd[:, k * chunk:(k + 1) * chunk]
+        outs.append(plan.exec(piece, chunk, hist=hist).cpu().numpy())
+        hist = torch.cat([hist, piece], dim=1)[:, -(nh - 1):].contiguous()
+    got = np.concatenate(outs, axis=1)
+    for c in range(nchan):
+        assert max(block_errors(got[c], whole[c])) <= TOL_FIR, (nh, chunk, c)
+
+
+def test_split_kernel_unaligned_rows(monkeypatch):
+    """Rows that start 4 and 12 bytes off a 16-byte boundary, row strides that are no multiple of
+    four samples, and nothing written outside the output rows."""
+    rng = np.random.default_rng(40)
+    h = oracle.windowed_sinc_taps(40).astype(np.float32)
+    plan = split_plan(h, monkeypatch)
+    big = torch.from_numpy(rng.uniform(-1, 1, (5, 9003)).astype(np.float32)).cuda()
+    x = big[:, 3:9000]
+    ybig = torch.zeros((5, 9101), dtype=torch.float32, device="cuda")
+    y = ybig[:, 1:9038]
+    plan.exec(x, 9037, y=y)
+    want = oracle.fir_batch_f32(x.cpu().numpy(), h, 9037)
+    got = y.cpu().numpy()
+    for c in range(5):
+        assert max(block_errors(got[c], want[c])) <= TOL_FIR
+    assert torch.all(ybig[:, 0] == 0) and torch.all(ybig[:, 9038:] == 0)
+
+
+def test_split_kernel_walks_tiles_across_rows(monkeypatch):
+    """Enough tiles that a workgroup walks several, with rows of 2.5 tiles: walks cross from one
+    row into the next, and every row has a ragged last tile."""
+    nh, nchan, nx = 127, 1500, 2 * 4096 + 2000
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = split_plan(h, monkeypatch)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
+    y = plan.exec(x, nx + nh)
+    for c in (0, 1, 2, 700, 1498, 1499):
+        want = oracle.fir_batch_f32(x[c:c + 1].cpu().numpy(), h, nx + nh)[0]
+        assert max(block_errors(y[c].cpu().numpy(), want)) <= TOL_FIR, c
+
+
+def test_split_kernel_wide_dynamic_range(monkeypatch):
+    """Samples spread over twelve decades: the three bf16 parts carry a float exactly at any
+    exponent, so the per-block error stays that of an f32 sum."""
+    nh = 127
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = split_plan(h, monkeypatch)
+    rng = np.random.default_rng(12)
+    nx = 6 * 4096
+    x = (rng.uniform(-1, 1, (2, nx)) * 10.0 ** rng.uniform(-6, 6, (2, nx))).astype(np.float32)
+    got = plan.exec(torch.from_numpy(x).cuda(), nx).cpu().numpy()
+    want = oracle.fir_batch_f32(x, h, nx)
+    for c in range(2):
+        assert max(block_errors(got[c], want[c])) <= TOL_FIR
+    # and tiny values keep their relative accuracy (no flush of the small parts)
+    xs = (x * 1e-30).astype(np.float32)
+    got = plan.exec(torch.from_numpy(xs).cuda(), nx).cpu().numpy()
+    want = oracle.fir_batch_f32(xs, h, nx)
+    for c in range(2):
+        assert max(block_errors(got[c], want[c])) <= TOL_FIR
