@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p
         const bool hist = valid && p.hist && sbase < 0;
         d.hbase = hist ? p.hist + (size_t)d.chan * p.hist_stride : p.x;
         d.hbytes = hist ? (int)(nh - 1) * 4 : 0;
-        d.hoff = (int)(sbase + nh - 1) * 4;
+        d.hoff = hist ? (int)(sbase + nh - 1) * 4 : 0;
         return d;
     };
 
@@ -749,6 +749,271 @@ __global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p
     for (long unit = 1; unit < nunits; unit++) iteration(unit);
 }
 
+// ---------------------------------------------------------------------------
+// f32 FIR on the f16 matrix pipe: operands split two ways, one scale per tile
+// ---------------------------------------------------------------------------
+//
+// The same tiling with half-precision parts.  A float scaled into [2^14, 2^15) is hi + lo + e
+// with hi = the value rounded to f16 (11 significant bits), lo = the remainder rounded, and
+// |e| <= 2^-23 of it; f16 reaches 2^-24 in absolute terms, so under one scale per tile -- the
+// power of two that brings the window's largest sample into that range -- a sample keeps this
+// relative accuracy down to 100 dB below the tile's peak, and below that the error stays
+// 2^-40 of the peak.  Taps are scaled and split the same way once, at plan creation.  Three
+// products are kept of the four (hi*hi, hi*lo, lo*hi; lo*lo is 2^-22 of the product), so a
+// slice costs three MFMAs instead of the six of the three-way bf16 split, two LDS planes
+// instead of three, and results are multiplied by the inverse scales on their way out.
+//
+// The scale of tile i+2 is found while tile i runs: its samples sit in the staging registers
+// (reissued during the first steps of the iteration, so that they have landed at its end),
+// every wave reduces its share to a maximum and leaves it in LDS ahead of the iteration's
+// barrier; the next iteration reads the four maxima, and splits the tile with that scale.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr size_t half_lds_bytes(int ns) { return (size_t)2 * 2 * (kSplitTile + 32 * ns - 16) * 2 + 64; }  // two sets of two planes + the maxima
+
+// f16(lo) in the low half, f16(hi) in the high half, both rounded to nearest even
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi)
+{
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// two floats, scaled -> their two f16 parts, packed pairwise; the subtractions are exact
+__device__ __forceinline__ void half_pair(float x0, float x1, float scale, unsigned &hi, unsigned &lo)
+{
+    const float s0 = x0 * scale, s1 = x1 * scale;
+    hi = cvt_pk_f16(s0, s1);
+    const f16x2 h = __builtin_bit_cast(f16x2, hi);
+    lo = cvt_pk_f16(s0 - (float)h[0], s1 - (float)h[1]);
+}
+
+// the largest value of a wave's lanes (non-negative inputs), returned in every lane
+__device__ __forceinline__ float wave_max(float v)
+{
+#define DSPMI_DPP_MAX(ctrl, row_mask) \
+    v = __builtin_fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false)))
+    DSPMI_DPP_MAX(0xb1, 0xf);    // quad_perm [1,0,3,2]
+    DSPMI_DPP_MAX(0x4e, 0xf);    // quad_perm [2,3,0,1]
+    DSPMI_DPP_MAX(0x141, 0xf);   // row_half_mirror
+    DSPMI_DPP_MAX(0x140, 0xf);   // row_mirror: every lane of a row of 16 holds the row's maximum
+    DSPMI_DPP_MAX(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    DSPMI_DPP_MAX(0x143, 0xc);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
+#undef DSPMI_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
+{
+    constexpr int P = 32 * NS - 16;          // window positions ahead of a block's first output
+    constexpr int NSTAGE = kSplitTile + P;   // samples staged per tile (a multiple of 16)
+    constexpr int NQ = NSTAGE / 4;           // ... in groups of four
+    constexpr int NIT = (NQ + 255) / 256;    // groups per lane (the last one on a few lanes only)
+    constexpr int NSTEP = 4 * NS;            // MFMA steps per wave and tile
+    static_assert(P / 4 <= 256, "the history falls into every lane's first group");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    unsigned short *lds = reinterpret_cast<unsigned short *>(smem_raw);  // [2][2][NSTAGE]
+    float *maxima = reinterpret_cast<float *>(lds + 4 * NSTAGE);          // [2][4]: per tile parity, per wave
+
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63, wave = t >> 6;
+    const long nx = p.nx, nh = p.nh;
+
+    f16x8 hf[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) hf[s][pl] = __builtin_bit_cast(f16x8, htab[(s * 2 + pl) * 64 + lane]);
+
+    const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
+    const long tile_hi = min(tile_lo + (long)p.tiles_per_block, (long)p.ntiles_total);
+    if (tile_hi <= tile_lo) return;
+    const long nunits = tile_hi - tile_lo;
+    unsigned cur_chan = (unsigned)(tile_lo / p.tiles_per_chan);
+    unsigned cur_tile = (unsigned)(tile_lo - (long)cur_chan * p.tiles_per_chan);
+
+    auto descriptor = [](const void *ptr, int bytes) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        void *base = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(base, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+
+    struct Unit {
+        const float *xbase, *hbase;  // first sample / first history sample the descriptors cover
+        int xbytes, hbytes;          // ... and how much (0: nothing to read)
+        int xoff, hoff;              // byte offset of the window's first sample from those
+        long tile_start;
+        unsigned chan;
+    };
+    long described = 0;
+    auto describe = [&]() {
+        Unit d;
+        const bool valid = described++ < nunits;  // a tile past this workgroup's last reads nothing
+        d.chan = valid ? cur_chan : 0;
+        d.tile_start = (long)cur_tile * kSplitTile;
+        if (++cur_tile == p.tiles_per_chan) {
+            cur_tile = 0;
+            ++cur_chan;
+        }
+        const long sbase = d.tile_start - P;          // the window is samples [sbase, sbase + NSTAGE)
+        const long lo = sbase < 0 ? 0 : sbase;
+        long n = min(nx, sbase + NSTAGE) - lo;
+        if (n < 0 || !valid) n = 0;
+        d.xbase = p.x + (size_t)d.chan * p.x_stride + lo;
+        d.xbytes = (int)n * 4;
+        d.xoff = (int)(sbase - lo) * 4;               // <= 0: an offset before the row is out of range
+        const bool hist = valid && p.hist && sbase < 0;
+        d.hbase = hist ? p.hist + (size_t)d.chan * p.hist_stride : p.x;
+        d.hbytes = hist ? (int)(nh - 1) * 4 : 0;
+        d.hoff = hist ? (int)(sbase + nh - 1) * 4 : 0;
+        return d;
+    };
+
+    f32x4 stage[NIT];
+    u32x4 hstage;  // the history's share of the first group (zero except in a row's first tile)
+    auto load_piece = [&](const Unit &d, int it) {
+        const unsigned u = t + 256 * it;
+        const int g = (int)(it < NIT - 1 || u < (unsigned)NQ ? u : (unsigned)NQ - 1) * 16;
+        const int xo = d.xoff + g;
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(descriptor(d.xbase, d.xbytes), xo < 0 ? 0x7ffffff0 : xo, 0, 0));
+        if (it == 0) {
+            const __amdgpu_buffer_rsrc_t hrsrc = descriptor(d.hbase, d.hbytes);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ho = d.hoff + g + 4 * e;
+                hstage[e] = __builtin_amdgcn_raw_buffer_load_b32(hrsrc, ho < 0 ? 0x7ffffff0 : ho, 0, 0);
+            }
+        }
+    };
+    auto put_piece = [&](unsigned short *planes, int it, float scale) {
+        const unsigned u = t + 256 * it;
+        if (it < NIT - 1 || u < (unsigned)NQ) {
+            unsigned h0, l0, h1, l1;
+            half_pair(stage[it][0], stage[it][1], scale, h0, l0);
+            half_pair(stage[it][2], stage[it][3], scale, h1, l1);
+            *reinterpret_cast<u32x2 *>(planes + 4 * u) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2 *>(planes + NSTAGE + 4 * u) = (u32x2){l0, l1};
+        }
+    };
+    // once the staging registers have landed: the history joins the first group, and the wave's
+    // largest magnitude goes to LDS for the tile of this parity
+    auto publish_max = [&](long tile_index) {
+        stage[0] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, stage[0]) | hstage);
+        float m = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; it++)
+            m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(stage[it][0]), __builtin_fabsf(stage[it][1])),
+                                                __builtin_fmaxf(__builtin_fabsf(stage[it][2]), __builtin_fabsf(stage[it][3]))), m);
+        m = wave_max(m);
+        if (lane == 0) maxima[(tile_index & 1) * 4 + wave] = m;
+    };
+    // the tile's scale, a power of two that brings its largest sample into [2^14, 2^15) (kept
+    // within 2^-100 .. 2^100), and the factor that takes a sum of scaled products back
+    auto scales = [&](long tile_index, float &scale, float &unscale) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(maxima + (tile_index & 1) * 4);
+        const float m = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
+        int e = 268 - (int)((__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)) >> 23) & 0xff);
+        e = e < 27 ? 27 : (e > 227 ? 227 : e);
+        scale = __builtin_bit_cast(float, e << 23);
+        unscale = __builtin_bit_cast(float, (254 - e) << 23) * tap_unscale;
+    };
+
+    // B operand: lane holds column a = lane&15 (block a of 16 outputs), window positions
+    // 8*(lane>>4) .. +7 of each slice
+    const unsigned b_base = wave * 1024 + 16 * (lane & 15) + 8 * (lane >> 4);
+
+    // prologue: the first tile is split with nothing to overlap it, the second is on its way
+    Unit cur = describe();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) load_piece(cur, it);
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) asm volatile("" : "+v"(hf[s][pl]));  // landed before the loop (see fir_split_kernel)
+    publish_max(0);
+    __syncthreads();
+    float scale_nxt, unscale_cur, unscale_nxt;
+    scales(0, scale_nxt, unscale_cur);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) put_piece(lds, it, scale_nxt);
+    Unit nxt = describe();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) load_piece(nxt, it);
+    publish_max(1);
+    __syncthreads();
+
+    // One tile: its MFMAs out of one set of planes; in its first steps the next tile's split into
+    // the other set and the loads of the tile after it; at its end that tile's maximum.  A step =
+    // one slice of one block of 256 outputs: two 16-byte reads, three MFMAs (48 cycles); reads run
+    // two steps ahead.  The leading products go to one accumulator and the two corrections to
+    // another: the small terms then round against each other, not against the running sum.
+    auto iteration = [&](long unit) {
+        const unsigned short *rd_planes = lds + (unit & 1) * (2 * NSTAGE);
+        unsigned short *wr_planes = lds + ((unit & 1) ^ 1) * (2 * NSTAGE);
+        const Unit nxt2 = describe();
+        scales(unit + 1, scale_nxt, unscale_nxt);
+        const long left = (long)p.nxx - cur.tile_start;
+        const __amdgpu_buffer_rsrc_t yrsrc = descriptor(p.y + (size_t)cur.chan * p.y_stride + cur.tile_start,
+                                                        (int)(left < kSplitTile ? left : kSplitTile) * 4);
+        f16x8 xf[3][2];
+        f32x4 big[4], small[4];
+        const unsigned short *xp = rd_planes + b_base;
+        auto rd = [&](int step) {
+            const int off = 256 * (step / NS) + 32 * (step % NS);
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+                xf[step % 3][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(xp + pl * NSTAGE + off));
+        };
+        auto store = [&](int q) {
+            u32x4 res;
+#pragma unroll
+            for (int r = 0; r < 4; r++) res[r] = __builtin_bit_cast(unsigned, (big[q][r] + small[q][r]) * unscale_cur);
+            const int off = (int)(wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) * 4;
+            __builtin_amdgcn_raw_buffer_store_b128(res, yrsrc, off, 0, 2);  // nontemporal
+        };
+        rd(0);
+        if (NSTEP > 1) rd(1);
+        int piece = 0;
+#pragma unroll
+        for (int step = 0; step < NSTEP; step++) {
+            const int q = step / NS, s = step % NS, slot = step % 3;
+            if (step + 2 < NSTEP) rd(step + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sm = s ? small[q] : zero, bg = s ? big[q] : zero;
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][0], xf[slot][1], sm, 0, 0, 0);
+            bg = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][0], xf[slot][0], bg, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][1], xf[slot][0], sm, 0, 0, 0);
+            small[q] = sm;
+            big[q] = bg;
+            // one piece per step from the first step on (all of them at once where a tile has
+            // fewer steps than pieces): the earlier a register is reloaded, the surer it has
+            // landed when the iteration ends
+#pragma unroll
+            for (; piece < NIT && (piece <= step || step == NSTEP - 1); piece++) {
+                put_piece(wr_planes, piece, scale_nxt);
+                load_piece(nxt2, piece);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0 && q > 0) store(q - 1);
+        }
+        store(3);
+        if (unit + 1 < nunits) {
+            publish_max(unit + 2);
+            __syncthreads();  // the other planes and the maxima are complete, and every wave has left these planes
+        }
+        cur = nxt;
+        nxt = nxt2;
+        unscale_cur = unscale_nxt;
+    };
+    iteration(0);  // a copy of the loop body, so that the loop is entered with its own order of memory operations
+    for (long unit = 1; unit < nunits; unit++) iteration(unit);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -770,6 +1035,9 @@ struct dspmi_fir_plan {
     // [slice][part][lane] register images, and its slice count
     void *split_tab = nullptr;
     int split_ns = 0;
+    // ... and of the f16 kernel, with the factor that undoes the scale the taps were split under
+    void *half_tab = nullptr;
+    float half_unscale = 1.f;
     char name[48] = "";
 };
 
@@ -878,6 +1146,114 @@ std::vector<unsigned short> split_tap_images(const float *taps, unsigned nh, int
     return img;
 }
 
+// float -> f16 bits, round to nearest even (|v| < 65520)
+inline unsigned short to_f16(float v)
+{
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    const unsigned short sign = (unsigned short)((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u >= 0x47800000u) return sign | 0x7c00;
+    if (u < 0x38800000u) {  // below 2^-14: a multiple of 2^-24
+        float f;
+        std::memcpy(&f, &u, 4);
+        return sign | (unsigned short)__builtin_rintf(f * 16777216.0f);
+    }
+    unsigned m = u - 0x38000000u;  // exponent bias 127 -> 15
+    m += 0xfffu + ((m >> 13) & 1u);
+    return sign | (unsigned short)(m >> 13);
+}
+inline float from_f16(unsigned short b)
+{
+    const int e = (b >> 10) & 31, m = b & 1023;
+    const float mag = e ? __builtin_ldexpf(1024.f + m, e - 25) : __builtin_ldexpf((float)m, -24);
+    return (b & 0x8000) ? -mag : mag;
+}
+
+// The A-operand images of fir_half_kernel, laid out like split_tap_images but with two f16 parts
+// of the taps times 2^k, k chosen so that the largest tap lies in [2^14, 2^15); *unscale = 2^-k.
+std::vector<unsigned short> half_tap_images(const float *taps, unsigned nh, int ns, float *unscale)
+{
+    const int P = 32 * ns - 16;
+    float peak = 0.f;
+    for (unsigned k = 0; k < nh; k++) peak = __builtin_fmaxf(peak, __builtin_fabsf(taps[k]));
+    int ex = 0;
+    if (peak > 0.f && peak < __builtin_inff()) (void)__builtin_frexpf(peak, &ex);  // peak = f * 2^ex, f in [0.5, 1)
+    int k2 = peak > 0.f ? 15 - ex : 0;
+    k2 = k2 < -100 ? -100 : (k2 > 100 ? 100 : k2);
+    *unscale = __builtin_ldexpf(1.f, -k2);
+    std::vector<unsigned short> part[2];
+    for (auto &v : part) v.assign(nh, 0);
+    for (unsigned k = 0; k < nh; k++) {
+        float r = __builtin_ldexpf(taps[k], k2);
+        for (int pl = 0; pl < 2; pl++) {
+            part[pl][k] = to_f16(r);
+            r -= from_f16(part[pl][k]);
+        }
+    }
+    std::vector<unsigned short> img((size_t)ns * 2 * 64 * 8, 0);
+    for (int s = 0; s < ns; s++)
+        for (int pl = 0; pl < 2; pl++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int m = 32 * s + 8 * (lane >> 4) + j, k = P + (lane & 15) - m;
+                    if (k >= 0 && k < (int)nh) img[(((size_t)s * 2 + pl) * 64 + lane) * 8 + j] = part[pl][k];
+                }
+    return img;
+}
+
+template <int NS>
+int launch_half_t(const FirParams<float> &p, const void *tab, float unscale, unsigned blocks, hipStream_t stream)
+{
+    size_t lds = half_lds_bytes(NS);
+    {
+        const char *env = getenv("DSPMI_FIR_BPC");  // experiments: cap the resident workgroups per CU
+        if (env && atoi(env) > 0) {
+            const size_t want = (160 * 1024) / atoi(env) - 512;
+            if (want > lds) lds = want;
+        }
+    }
+    auto kern = fir_half_kernel<NS>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, p, static_cast<const u32x4 *>(tab), unscale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int launch_half(FirParams<float> p, const void *tab, float unscale, int ns, unsigned nchan, hipStream_t stream)
+{
+    p.tiles_per_chan = (unsigned)(((unsigned long long)p.nxx + kSplitTile - 1) / kSplitTile);
+    const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
+    if (tiles == 0) return DSPMI_OK;
+    if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
+    p.ntiles_total = (unsigned)tiles;
+    // a workgroup's first two tiles are loaded with nothing to overlap them: long walks
+    unsigned tpb = (unsigned)(tiles / 4096);
+    p.tiles_per_block = tpb < 2 ? (tiles >= 2048 ? 2 : 1) : (tpb > 32 ? 32 : tpb);
+    {
+        const char *env = getenv("DSPMI_FIR_TPB");  // experiment knob
+        if (env && atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
+    }
+    const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
+    switch (ns) {
+    case 1: return launch_half_t<1>(p, tab, unscale, blocks, stream);
+    case 2: return launch_half_t<2>(p, tab, unscale, blocks, stream);
+    case 3: return launch_half_t<3>(p, tab, unscale, blocks, stream);
+    case 4: return launch_half_t<4>(p, tab, unscale, blocks, stream);
+    case 5: return launch_half_t<5>(p, tab, unscale, blocks, stream);
+    case 6: return launch_half_t<6>(p, tab, unscale, blocks, stream);
+    case 7: return launch_half_t<7>(p, tab, unscale, blocks, stream);
+    case 8: return launch_half_t<8>(p, tab, unscale, blocks, stream);
+    case 9: return launch_half_t<9>(p, tab, unscale, blocks, stream);
+    case 10: return launch_half_t<10>(p, tab, unscale, blocks, stream);
+    }
+    return dspmi::fail(DSPMI_EINVAL, "fir: no f16 kernel of %d slices", ns);
+}
+
 template <int NS>
 int launch_split_t(const FirParams<float> &p, const void *tab, unsigned blocks, hipStream_t stream)
 {
@@ -931,10 +1307,11 @@ int launch_split(FirParams<float> p, const void *tab, int ns, unsigned nchan, hi
 }
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
-// Tap counts the bf16 kernel takes by default (measured, 512 x 2^20 samples: 63 taps 0.80 ms against
-// 0.93 for the f32 matrix kernel; 127 taps 0.95-0.98 against 1.03 for overlap-save; from about 150
-// taps overlap-save wins, below 33 the f32 kernel is as fast).
-constexpr unsigned kSplitAutoMinTaps = 33, kSplitAutoMaxTaps = 145;
+// The f16 kernel takes every tap count its ten slices hold, from where the f32 matrix kernel stops
+// being as fast (measured, 512 x 2^20 samples: 33 taps 0.82 ms against 0.80; 63 taps 0.82 against
+// 0.93; 127 taps 0.82 against 1.03 for overlap-save and 0.98 for the bf16 kernel; 305 taps 1.09
+// against 1.16 for overlap-save).
+constexpr unsigned kSplitAutoMinTaps = 40;
 constexpr unsigned kOlsMinTaps = 64;  // measured crossover (direct 1.12 ms vs 1.08 at 64 taps; direct wins below)
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
@@ -986,29 +1363,34 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
     if (precision == DSPMI_F64) {
         pl->variant = V_F64_EXACT;
     } else {
-        // A/B knob: "valu", "mfma" (the f32 matrix kernel), "bf16" (the split kernel wherever it
-        // applies) or "ols" (overlap-save from kOlsMinTaps up) pin that path; anything else is automatic
+        // A/B knob: "valu", "mfma" (the f32 matrix kernel), "f16" / "bf16" (the two split kernels,
+        // wherever they apply) or "ols" (overlap-save from kOlsMinTaps up) pin that path; anything
+        // else is automatic
         const char *env = getenv("DSPMI_FIR_VARIANT");
         const bool valu = env && !strcmp(env, "valu"), mfma = env && !strcmp(env, "mfma");
-        const bool want_split = env && !strcmp(env, "bf16"), want_ols = env && !strcmp(env, "ols");
+        const bool want_bf16 = env && !strcmp(env, "bf16"), want_ols = env && !strcmp(env, "ols");
+        const bool want_half = !want_bf16, want_split = want_bf16 || (env && !strcmp(env, "f16"));
         pl->variant = valu ? (nh <= 32 ? V_F32_SHORT : V_F32_LONG) : V_F32_MFMA;
         if constexpr (sizeof(T) == 4) {
-            const unsigned split_max = want_split ? 32 * kSplitMaxSlices - 15 : kSplitAutoMaxTaps;
-            if (!valu && !mfma && !want_ols && nh >= kSplitAutoMinTaps && nh <= split_max) {
+            const unsigned split_max = 32 * kSplitMaxSlices - 15;
+            if (!valu && !mfma && !want_ols && nh >= (want_split ? 1u : kSplitAutoMinTaps) && nh <= split_max) {
                 pl->split_ns = (int)((nh + 15 + 31) / 32);
-                const std::vector<unsigned short> img = split_tap_images(taps, nh, pl->split_ns);
+                const std::vector<unsigned short> img = want_half ? half_tap_images(taps, nh, pl->split_ns, &pl->half_unscale)
+                                                                  : split_tap_images(taps, nh, pl->split_ns);
+                void **tab = want_half ? &pl->half_tab : &pl->split_tab;
                 e = hipSetDevice(device);
-                if (e == hipSuccess) e = hipMalloc(&pl->split_tab, img.size() * 2);
-                if (e == hipSuccess) e = hipMemcpy(pl->split_tab, img.data(), img.size() * 2, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMalloc(tab, img.size() * 2);
+                if (e == hipSuccess) e = hipMemcpy(*tab, img.data(), img.size() * 2, hipMemcpyHostToDevice);
                 (void)hipSetDevice(prev);
                 if (e != hipSuccess) {
                     (void)hipFree(pl->split_tab);
+                    (void)hipFree(pl->half_tab);
                     (void)hipFree(pl->taps_dev);
                     delete pl;
                     return dspmi::fail(DSPMI_EIO, "fir_create: %s", hipGetErrorString(e));
                 }
             }
-            if (!valu && !mfma && !pl->split_tab && nh >= kOlsMinTaps && nh <= 8192) {
+            if (!valu && !mfma && !pl->split_tab && !pl->half_tab && nh >= kOlsMinTaps && nh <= 8192) {
                 // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
                 // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384; beyond 2048
                 // taps the plan's own default (32768-point blocks)
@@ -1020,7 +1402,8 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
             }
         }
     }
-    if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
+    if (pl->half_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_f16x2_mfma16x16x32_s%d", pl->split_ns);
+    else if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
     else snprintf(pl->name, sizeof pl->name, "%s", kVariantName[pl->variant]);
     *out = pl;
@@ -1050,6 +1433,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
         if (pl->ols && flags == 0 && nxx == nx && nx >= 2 * pl->ols_n)
             return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+        if (pl->half_tab && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
             return launch_mfma(p, nchan, s);
@@ -1095,6 +1479,7 @@ int dspmi_fir_destroy(dspmi_fir_t plan)
     if (!plan) return DSPMI_OK;
     if (plan->ols) (void)dspmi_ols_destroy(plan->ols);
     (void)hipFree(plan->split_tab);
+    (void)hipFree(plan->half_tab);
     hipError_t e = hipFree(plan->taps_dev);
     delete plan;
     if (e != hipSuccess) return dspmi::fail(DSPMI_EIO, "fir_destroy: %s", hipGetErrorString(e));

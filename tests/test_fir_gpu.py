@@ -85,7 +85,7 @@ def test_wrapper_long_kernel_multi_segment():
 @pytest.fixture(params=["auto", "mfma", "ols"])
 def fir_path(request, monkeypatch):
     """A plan picks its kernel by tap count (the f32 matrix kernel for the shortest filters, the
-    bf16 split kernel in the middle, overlap-save for long filters on long rows); "mfma" pins
+    f16 split kernel in the middle, overlap-save for long filters on long rows); "mfma" pins
     the f32 matrix kernel and "ols" overlap-save from 64 taps up, so all three are checked on
     the same cases."""
     if request.param != "auto":
@@ -227,7 +227,7 @@ def test_linearity_and_impulse_at_scale(fir_path):
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     plan = dsp_amd.FirPlan(h, "f32")
     assert ("overlap_save" in plan.variant) == (fir_path == "ols")
-    assert ("bf16" in plan.variant) == (fir_path == "auto")
+    assert ("f16x2" in plan.variant) == (fir_path == "auto")
     g = torch.Generator(device="cuda").manual_seed(1)
     a = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
     b = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
@@ -238,11 +238,14 @@ def test_linearity_and_impulse_at_scale(fir_path):
     imp[0, 0] = 1.0
     imp[1, nx - 200] = 1.0
     yi = plan.exec(imp).cpu().numpy()
-    if fir_path != "ols":
-        # one product per output, added to zeros: the taps come back exactly (in the split kernel
-        # the sample 1.0 is its own leading part, and a tap's three parts add up to it exactly)
+    if fir_path == "mfma":
+        # one product per output, added to zeros: the taps come back exactly
         assert np.array_equal(yi[0, :nh], h) and not yi[0, nh:].any()
         assert np.array_equal(yi[1, nx - 200:nx - 200 + nh], h) and not yi[1, :nx - 200].any()
+    elif fir_path == "auto":
+        # the taps as the sum of their two f16 parts (22 bits), and exact zeros elsewhere
+        assert rel_l2(yi[0, :nh], h) <= 2.0 ** -22 and not yi[0, nh:].any()
+        assert rel_l2(yi[1, nx - 200:nx - 200 + nh], h) <= 2.0 ** -22 and not yi[1, :nx - 200].any()
     else:
         # through the transforms: the taps to rounding, and rounding noise elsewhere
         hn = np.linalg.norm(h)
@@ -328,20 +331,41 @@ def test_in_place_is_refused_interleaved_rows_are_not(fir_path):
 
 # ---- the bf16 split kernel (17..305 taps) ---------------------------------------------
 
-def split_plan(h, monkeypatch):
-    monkeypatch.setenv("DSPMI_FIR_VARIANT", "bf16")
+@pytest.fixture(params=["bf16", "f16"])
+def split_kind(request):
+    """The two kernels that split f32 operands for the 16-bit matrix pipe: three bf16 parts, or
+    two f16 parts under a per-tile scale."""
+    return request.param
+
+
+def assert_blocks(got, want, h, x, what, blk=4096):
+    """Every 4096-sample block within TOL_FIR of its own norm, plus the absolute floor of the
+    16-bit parts: a tap or sample more than 2^39 below the largest of its tile is not carried
+    (outputs that are sums of such terms alone -- the first output under a window whose edge tap
+    is 1e-18 -- come out as zero)."""
+    floor = 2.0 ** -37 * np.sqrt(len(h)) * np.abs(h).max() * max(np.abs(x).max(), 1e-300)
+    edges = list(range(0, len(want), blk)) + [len(want)]
+    if len(edges) > 2 and edges[-1] - edges[-2] < blk // 4:
+        del edges[-2]
+    for a, b in zip(edges, edges[1:]):
+        err = np.linalg.norm(got[a:b].astype(np.float64) - want[a:b])
+        assert err <= TOL_FIR * np.linalg.norm(want[a:b]) + floor * np.sqrt(b - a), (what, a, err, np.linalg.norm(want[a:b]))
+
+
+def split_plan(h, monkeypatch, kind):
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", kind)
     plan = dsp_amd.FirPlan(h, "f32")
-    assert "bf16" in plan.variant, plan.variant
+    assert kind in plan.variant, plan.variant
     return plan
 
 
 @pytest.mark.parametrize("nh", [17, 18, 48, 49, 100, 127, 177, 178, 256, 305])
-def test_split_kernel_every_slice_count(nh, monkeypatch):
+def test_split_kernel_every_slice_count(nh, monkeypatch, split_kind):
     """One tap count at and one past the edges of the 32-position slices (nh + 15 = 32 k), ragged
     rows of every length class: shorter than a tile, a tile plus a few, rows that end inside a
     16-byte group; outputs cut at nx and run on to nx + nh."""
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
-    plan = split_plan(h, monkeypatch)
+    plan = split_plan(h, monkeypatch, split_kind)
     rng = np.random.default_rng(nh)
     for nx, nchan in [(3, 2), (nh - 1, 1), (4095, 3), (4097, 2), (9001, 3), (3 * 4096 + 2, 2)]:
         x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
@@ -350,16 +374,16 @@ def test_split_kernel_every_slice_count(nh, monkeypatch):
             got = plan.exec(xd, nxx).cpu().numpy()
             want = oracle.fir_batch_f32(x, h, nxx)
             for c in range(nchan):
-                assert max(block_errors(got[c], want[c])) <= TOL_FIR, (nh, nx, nxx, c)
+                assert_blocks(got[c], want[c], h, x[c], (nh, nx, nxx, c))
 
 
 @pytest.mark.parametrize("nh,chunk", [(127, 8192), (100, 5000), (33, 4096), (305, 4097), (64, 300)])
-def test_split_kernel_streaming_history(nh, chunk, monkeypatch):
+def test_split_kernel_streaming_history(nh, chunk, monkeypatch, split_kind):
     """A row cut in chunks with the previous chunk's tail as history gives the row's outputs; tap
     counts whose history does not line up with the 16-byte groups of the window, chunks shorter
     than the history included."""
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
-    plan = split_plan(h, monkeypatch)
+    plan = split_plan(h, monkeypatch, split_kind)
     rng = np.random.default_rng(nh + chunk)
     nchan, nchunk = 3, 4
     x = rng.uniform(-1, 1, (nchan, nchunk * chunk)).astype(np.float32)
@@ -376,12 +400,12 @@ def test_split_kernel_streaming_history(nh, chunk, monkeypatch):
         assert max(block_errors(got[c], whole[c])) <= TOL_FIR, (nh, chunk, c)
 
 
-def test_split_kernel_unaligned_rows(monkeypatch):
+def test_split_kernel_unaligned_rows(monkeypatch, split_kind):
     """Rows that start 4 and 12 bytes off a 16-byte boundary, row strides that are no multiple of
     four samples, and nothing written outside the output rows."""
     rng = np.random.default_rng(40)
     h = oracle.windowed_sinc_taps(40).astype(np.float32)
-    plan = split_plan(h, monkeypatch)
+    plan = split_plan(h, monkeypatch, split_kind)
     big = torch.from_numpy(rng.uniform(-1, 1, (5, 9003)).astype(np.float32)).cuda()
     x = big[:, 3:9000]
     ybig = torch.zeros((5, 9101), dtype=torch.float32, device="cuda")
@@ -394,12 +418,12 @@ def test_split_kernel_unaligned_rows(monkeypatch):
     assert torch.all(ybig[:, 0] == 0) and torch.all(ybig[:, 9038:] == 0)
 
 
-def test_split_kernel_walks_tiles_across_rows(monkeypatch):
+def test_split_kernel_walks_tiles_across_rows(monkeypatch, split_kind):
     """Enough tiles that a workgroup walks several, with rows of 2.5 tiles: walks cross from one
     row into the next, and every row has a ragged last tile."""
     nh, nchan, nx = 127, 1500, 2 * 4096 + 2000
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
-    plan = split_plan(h, monkeypatch)
+    plan = split_plan(h, monkeypatch, split_kind)
     g = torch.Generator(device="cuda").manual_seed(5)
     x = torch.rand((nchan, nx), device="cuda", generator=g) * 2 - 1
     y = plan.exec(x, nx + nh)
@@ -408,12 +432,12 @@ def test_split_kernel_walks_tiles_across_rows(monkeypatch):
         assert max(block_errors(y[c].cpu().numpy(), want)) <= TOL_FIR, c
 
 
-def test_split_kernel_wide_dynamic_range(monkeypatch):
+def test_split_kernel_wide_dynamic_range(monkeypatch, split_kind):
     """Samples spread over twelve decades: the three bf16 parts carry a float exactly at any
     exponent, so the per-block error stays that of an f32 sum."""
     nh = 127
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
-    plan = split_plan(h, monkeypatch)
+    plan = split_plan(h, monkeypatch, split_kind)
     rng = np.random.default_rng(12)
     nx = 6 * 4096
     x = (rng.uniform(-1, 1, (2, nx)) * 10.0 ** rng.uniform(-6, 6, (2, nx))).astype(np.float32)

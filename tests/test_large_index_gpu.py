@@ -1,5 +1,5 @@
 """Rows and batches whose element and byte offsets pass 2^31 and 2^32: one channel of
-2^31 + 5000 samples through both FIR kernels, and a c2c batch of more than 2^32 complex points.
+2^31 + 5000 samples through every FIR kernel, and a c2c batch of more than 2^32 complex points.
 Checked on windows around the offsets where a 32-bit byte or element index would wrap."""
 import numpy as np
 import pytest
@@ -16,17 +16,18 @@ def rel_l2(got, want):
 
 
 @pytest.mark.parametrize("nh,path,nx", [(16, "direct", (1 << 31) + 5000), (127, "overlap_save", (1 << 31) + 5000),
-                                        (127, "direct", (1 << 31) + 5000),
+                                        (127, "direct", (1 << 31) + 5000), (127, "bf16", (1 << 31) + 5000),
+                                        (127, "f16", (1 << 31) + 5000),
                                         # the longest row the 32-bit sample count can express
-                                        (127, "overlap_save", (1 << 32) - 3), (16, "direct", (1 << 32) - 3)])
+                                        (127, "overlap_save", (1 << 32) - 3), (16, "direct", (1 << 32) - 3),
+                                        (127, "f16", (1 << 32) - 3)])
 def test_fir_row_longer_than_2_31_samples(nh, path, nx, monkeypatch):
     if torch.cuda.mem_get_info()[0] < 60 << 30:
         pytest.skip("needs 60 GiB of free device memory")
-    if path == "direct":
-        monkeypatch.setenv("DSPMI_FIR_VARIANT", "mfma")
+    monkeypatch.setenv("DSPMI_FIR_VARIANT", {"direct": "mfma", "overlap_save": "ols", "bf16": "bf16", "f16": "f16"}[path])
     h = (np.asarray(oracle.TAPS16) if nh == 16 else oracle.windowed_sinc_taps(nh)).astype(np.float32)
     plan = dsp_amd.FirPlan(h, "f32")
-    assert ("overlap_save" in plan.variant) == (path == "overlap_save")
+    assert ("overlap_save" in plan.variant) == (path == "overlap_save") and ("bf16" in plan.variant) == (path == "bf16") and ("f16x2" in plan.variant) == (path == "f16")
     g = torch.Generator(device="cuda").manual_seed(nh)
     x = torch.rand((1, nx), device="cuda", generator=g) * 2 - 1
     y = plan.exec(x)

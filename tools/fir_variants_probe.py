@@ -34,12 +34,12 @@ def block_err(yrow, xrow, h):
 for nh in taps_list:
     h = (np.asarray(oracle.TAPS16) if nh == 16 else oracle.windowed_sinc_taps(nh)).astype(np.float32)
     line = "taps %4d:" % nh
-    for variant in ("bf16", "mfma", "ols"):
+    for variant in ("f16", "bf16", "mfma", "ols"):
         os.environ["DSPMI_FIR_VARIANT"] = variant
         plan = dsp_amd.FirPlan(h, "f32")
         del os.environ["DSPMI_FIR_VARIANT"]
         name = plan.variant
-        if variant == "bf16" and "bf16" not in name or variant == "ols" and "overlap" not in name:
+        if variant in ("bf16", "f16") and variant not in name or variant == "ols" and "overlap" not in name:
             continue
         y.zero_()
         for _ in range(3):
