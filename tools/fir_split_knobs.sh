@@ -1,10 +1,6 @@
 #!/bin/bash
-# bf16 FIR kernel: tiles per workgroup and resident workgroups per CU, 31 and 127 taps
-for tpb in 1 2 4 8 16 32; do
+# f16 FIR kernel: tiles per workgroup (512 channels x 2^20 samples = 131072 tiles), 127 and 305 taps
+for tpb in 4 8 16 32 43 57 86 171 342; do
   echo "== DSPMI_FIR_TPB=$tpb"
-  DSPMI_FIR_TPB=$tpb timeout -k 10 120 python tools/fir_variants_probe.py 512 31 127 || exit 1
-done
-for bpc in 1 2 3; do
-  echo "== DSPMI_FIR_BPC=$bpc"
-  DSPMI_FIR_BPC=$bpc timeout -k 10 120 python tools/fir_variants_probe.py 512 31 127 || exit 1
+  DSPMI_FIR_TPB=$tpb timeout -k 10 120 python tools/fir_variants_probe.py 512 63 127 305 | cut -c1-60 || exit 1
 done

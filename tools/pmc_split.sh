@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the bf16 FIR kernel on the bench's 127-tap workload, three passes
+# SQ counters of the FIR kernel the plan picks on the bench's 127-tap workload, three passes
 export TMPDIR=/tmp
 w=${1:-fir127}
 p1="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES"
@@ -11,5 +11,5 @@ for ctr in "$p1" "$p2" "$p3"; do
   rm -rf gpurun_out/pmcs_$i
   timeout -s KILL 120 rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/pmcs_$i -o p -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/pmcs_$i.log 2>&1 || { tail -5 gpurun_out/pmcs_$i.log; exit 1; }
   f=$(find gpurun_out/pmcs_$i -name "*counter_collection.csv" | head -1)
-  python3 tools/pmc_summary.py $f fir_split
+  python3 tools/pmc_summary.py $f fir_
 done
