@@ -70,11 +70,18 @@ int dspmi_device_count(void);
 typedef struct dspmi_fir_plan *dspmi_fir_t;
 
 /* taps: nh HOST values, h[0] first.  device < 0 means the current device.
- * An f32 plan of 64..8192 taps also prepares an overlap-save path (the frequency-domain
- * convolution doc/notes:81-82 names; same outputs to the same 1e-6 bound with fewer flops),
- * which dspmi_fir_exec_f32 uses when flags == 0, nxx == nx and the rows hold at least two
- * transforms; every other call runs the direct kernel.  DSPMI_FIR_VARIANT=mfma in the
- * environment at creation pins the direct kernel. */
+ * An f32 plan picks its kernel by tap count, every choice within the same 1e-6 (relative L2 per
+ * 4096 outputs) of the double sum:
+ *   up to 39 taps   f32 multiply-accumulate chains on the matrix unit;
+ *   40 .. 305       the same sum through the f16 matrix pipe: samples and taps as two f16 parts
+ *                   each, under one power-of-two scale per 4096-output tile, accumulated in f32.
+ *                   A sample more than 2^39 below the largest of its tile is not carried, and a
+ *                   non-finite sample makes its whole tile non-finite;
+ *   306 .. 8192     overlap-save (the frequency-domain convolution doc/notes:81-82 names) when
+ *                   flags == 0, nxx == nx and the rows hold at least two transforms; any other
+ *                   call, and longer filters, run the f32 kernel.
+ * DSPMI_FIR_VARIANT = mfma | f16 | bf16 | ols in the environment at creation pins the f32 kernel,
+ * the f16 kernel, its three-part bf16 sibling (no scale, full f32 exponent range) or overlap-save. */
 int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device);
 int dspmi_fir_create_f64(dspmi_fir_t *plan, const double *taps, unsigned nh, int device);
 int dspmi_fir_destroy(dspmi_fir_t plan);
