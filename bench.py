@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir127_direct", "fir16", "c1", "fir8191", "ols8191",
                                                              "ols8191_split", "chain"])
     ap.add_argument("--ols-n", type=int, default=0, help="8191-tap overlap-save: transform length (0 = the plan's choice)")
+    ap.add_argument("--chain-two-kernels", action="store_true", help="chain workload: FIR and real transform as two kernels (A/B)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
@@ -274,10 +275,15 @@ def make_chain(args, rank):
     ps = torch.empty((nchan * chunk // nfft, nfft // 2 + 1), dtype=torch.float32, device="cuda")
     hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
 
+    fused = "f16x2" in fir.variant and not args.chain_two_kernels
+
     def filter_and_transform():
-        fir.exec(x, chunk, y=y, hist=hist)
+        if fused:
+            fir.spectrum(fft, x, hist=hist, out=ps)      # FIR -> r2c -> |X| / sum in one kernel: y never reaches HBM
+        else:
+            fir.exec(x, chunk, y=y, hist=hist)
+            fft.r2c_spectrum(y.view(-1, nfft), out=ps)   # r2c + |X| + normalise in one pass
         hist.copy_(x[:, chunk - (nh - 1):])
-        fft.r2c_spectrum(y.view(-1, nfft), out=ps)   # r2c + |X| + normalise in one pass
 
     def step():
         for _ in range(nchunk):
@@ -295,11 +301,13 @@ def make_chain(args, rank):
     fir_fft_ms = (time.perf_counter() - t0) * 1e3 / 3
 
     units = nchan * chunk * nchunk
-    info = dict(kernel="tonegen + %s + r2c_spectrum(%s)" % (fir.variant, fft.variant), units=units, unit_name="samples",
+    info = dict(kernel=("tonegen + fir_spectrum(%s, n%d)" % (fir.variant, nfft)) if fused else
+                "tonegen + %s + r2c_spectrum(%s)" % (fir.variant, fft.variant), units=units, unit_name="samples",
                 nh=nh, flop_per_unit=2.0 * nh + 2.5 * math.log2(nfft), bytes_per_unit=4.0 + 2.0, bound="hbm",
                 samples_per_unit=1, fir_fft_ms=fir_fft_ms,
                 note="algorithmic bytes: 4 B per generated sample + 2 B of spectrum per sample (N/2+1 floats per N samples); "
-                     "the stages hand their results on through HBM, which the roof does not allow for",
+                     + ("the generator hands its samples on through HBM (4 B written + 4 B read per sample), the filtered samples stay on chip"
+                        if fused else "the stages hand their results on through HBM, which the roof does not allow for"),
                 workload="chain: tones -> %d-tap FIR -> N=%d r2c -> |X|/sum, %d channels x %d samples in %d chunks"
                          % (nh, nfft, nchan, chunk * nchunk, nchunk))
     return step, info, (gen, x, fir, fft, y, ps, hist)

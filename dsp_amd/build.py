@@ -19,14 +19,15 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno
 # source -> extra flags.  fir_direct keeps products and sums as written (its
 # fused multiply-adds are explicit), which the bit-exact double path relies on;
 # MFMA accumulators stay in ordinary VGPRs (gfx950 has one unified file), which
-# keeps hipcc from shuffling them through AGPR copies inside the tap loop.
+# keeps hipcc from shuffling them through AGPR copies inside the tap loop (fft_stockham holds the
+# FIR + spectrum kernel, hence the same flag there).
 # fft_stockham is built without the SLP vectoriser: a packed f32 instruction issues at half the
 # rate of a plain one on gfx950 (no throughput to gain), and pairing the butterflies' scalars
 # costs a register move for every third instruction and 30-40 more VGPRs.
 SOURCES = {
     "runtime.cpp": ["-x", "hip"],
     "fir_direct.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"],
-    "fft_stockham.hip": ["-fno-slp-vectorize"],
+    "fft_stockham.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
     "fft_plan.hip": [],
     "ols.hip": [],
     "spectrum.hip": [],

@@ -61,6 +61,10 @@ struct PerDeviceOnce {
     void mark() { done.fetch_or(bit(), std::memory_order_release); }
 };
 
+// The f16 matrix-pipe form of an f32 FIR plan's taps (fir_direct.hip): the register images, the
+// factor that undoes the taps' scale, the slice count.  Fails when the plan runs another kernel.
+int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *slices, unsigned *nh, int *device);
+
 }  // namespace dspmi
 
 // Device-API check: record the failing call and return DSPMI_EIO.

@@ -58,4 +58,24 @@ typedef int (*bluestein_launch_fn)(const void *in, void *out, const void *chirp,
                                    size_t batch, int backward, int num_cu, hipStream_t s);
 bluestein_launch_fn bluestein_find(unsigned m, int precision);
 
+// FIR (the f16 matrix-pipe kernel of a FIR plan) -> 4096-point real transform -> normalised
+// magnitude spectrum in one kernel.  x: nchan rows of nx samples, nx a multiple of 4096; ps:
+// nchan * nx / 4096 rows of nbin (2048 or 2049) floats.  tap_images / tap_unscale / slices come
+// from the FIR plan, tw_half = exp(-2 pi i k / 2048), tw_full = exp(-2 pi i k / 4096) from a
+// 4096-point FFT plan.  All pointers are device pointers.
+struct FirSpectrumLaunch {
+    const float *x, *hist;
+    size_t x_stride, hist_stride;
+    unsigned nx, nh, nchan;
+    const void *tap_images;
+    float tap_unscale;
+    int slices;
+    const void *tw_half, *tw_full;
+    float *ps;
+    unsigned nbin;
+    int mode;
+    float scale;
+};
+int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s);
+
 }  // namespace dspmi

@@ -932,6 +932,42 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
     return dspmi_power_spectrum_f32(ps, plan->work[2], nbin, n / 2 + 1, batch, mode, scale, stream);
 }
 
+int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode, float scale, const float *x,
+                           size_t x_stride, unsigned nx, unsigned nchan, const float *hist, size_t hist_stride, void *stream)
+{
+    if (!fir || !fft) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: null plan");
+    if (int rc = dspmi::check_device(fft->device, "fir_spectrum")) return rc;
+    dspmi::FirSpectrumLaunch a{};
+    int fir_device = -1;
+    if (int rc = dspmi::fir_half_images(fir, &a.tap_images, &a.tap_unscale, &a.slices, &a.nh, &fir_device)) return rc;
+    if (fir_device != fft->device) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: the two plans belong to different devices");
+    if (fft->precision != DSPMI_F32 || fft->n != 4096 || !fused_real(fft))
+        return dspmi::fail(DSPMI_ENOSYS, "fir_spectrum: needs an f32 transform plan of 4096 points");
+    if (nchan == 0 || nx == 0) return DSPMI_OK;
+    if (nx % 4096) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: rows must hold whole frames of 4096 samples");
+    if (!x || !ps) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: null buffer");
+    if (x_stride < nx) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: stride smaller than the row length");
+    if (hist && hist_stride + 1 < a.nh) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: hist_stride < nh-1");
+    if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: mode must be 0, 1 or 2");
+    if (nbin != 2048 && nbin != 2049) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: nbin must be 2048 or 2049");
+    const size_t frames = (size_t)nchan * (nx / 4096);
+    if (ranges_overlap(x, ((size_t)(nchan - 1) * x_stride + nx) * sizeof(float), ps, frames * nbin * sizeof(float)))
+        return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: the spectrum buffer overlaps the input");
+    a.x = x;
+    a.hist = hist;
+    a.x_stride = x_stride;
+    a.hist_stride = hist_stride;
+    a.nx = nx;
+    a.nchan = nchan;
+    a.tw_half = fft->tw_half;
+    a.tw_full = fft->tw_n;
+    a.ps = ps;
+    a.nbin = nbin;
+    a.mode = mode;
+    a.scale = scale;
+    return dspmi::fir_spectrum_launch(a, static_cast<hipStream_t>(stream));
+}
+
 int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float *ps, size_t batch, unsigned nbin, int mode,
                                       float scale, void *stream)
 {

@@ -28,6 +28,7 @@
 // The backward transform is conj(forward(conj(x))).
 #include "common.h"
 #include "fft_internal.h"
+#include "fir_half.h"
 
 #include <cmath>
 #include <cstdint>
@@ -687,6 +688,148 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// FIR -> 4096-point real transform -> normalised magnitude spectrum, in one kernel
+// ---------------------------------------------------------------------------
+
+// The chain of alsa/main.c:542-568 after the tone generator: do_fir, then do_power_spectrum on
+// frames of 4096 filtered samples.  A tile of the f16 FIR walker (fir_half.h) is 4096 outputs,
+// i.e. one frame, so its results go into an LDS frame image instead of HBM, and once the tile's
+// MFMAs are done the workgroup's 256 lanes run the frame's packed 2048-point complex transform
+// (8 points per lane, radices 8.8.8.4, split twiddle tables), form the bins from Z[k] and
+// Z[N-k], take magnitudes, sum, normalise and store: 4 B read and 2 B written per sample where
+// the two kernels move 14.  Every memory instruction of the epilogue is unconditional (a store
+// that must not happen goes to an out-of-range offset of its descriptor), so the walker's
+// prefetch keeps its exact wait counts.
+template <int NS>
+struct SpectrumSink {
+    static constexpr bool kTileHook = true;
+    static constexpr int N = 2048, NT = 256, R0 = 8, R1 = 8, R2 = 8, R3 = 4, TW = 3, P = N / NT;
+    C<float> *img;                    // the frame image, padded_len(N) complex
+    const C<float> *tw1, *tw2, *tw3;  // LDS twiddle tables
+    const C<float> *tw, *tw2n;        // exp(-2 pi i k / N), exp(-2 pi i k / 2N) in device memory
+    float *scratch;                   // the waves' partial sums
+    float *ps;
+    unsigned nbin, frames_per_chan;
+    int mode;
+    float scale;
+    size_t frame;
+
+    __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start)
+    {
+        frame = (size_t)chan * frames_per_chan + (size_t)(tile_start / kSplitTile);
+    }
+    // four consecutive real results = two consecutive complex points of the packed frame
+    __device__ __forceinline__ void emit(int q, f32x4 res)
+    {
+        const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned j = (wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) / 2;  // even: j and j+1 share a padding group
+        img[pad(j)] = {res[0], res[1]};
+        img[pad(j) + 1] = {res[2], res[3]};
+    }
+    __device__ __forceinline__ void end_tile()
+    {
+        unsigned tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));  // keeps the addresses below out of the walker's loop-invariant registers
+        C<float> v[P];
+#pragma unroll
+        for (int r = 0; r < R0; r++) v[r] = img[pad(tl + r * (N / R0))];
+        __syncthreads();  // every lane holds its inputs before the first pass writes the image
+        run_passes<float, N, NT, R0, R1, R2, R3, TW>(v, img, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
+#pragma unroll
+        for (int b = 0; b < P / R3; b++)
+#pragma unroll
+            for (int r = 0; r < R3; r++) img[pad(tl + NT * b + r * (N / R3))] = v[b * R3 + r];
+        __syncthreads();
+
+        // bins in pairs, as in fft_r2c_kernel: X[k] = E[k] + W^k O[k], X[N-k] = conj(E[k] - W^k O[k])
+        constexpr int H = P / 2;
+        float mlo[H], mhi[H];
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const unsigned k = tl + NT * i;
+            const C<float> a = img[pad(k)];
+            const C<float> b0 = img[pad((N - k) & (N - 1))];
+            const C<float> e = {(a.re + b0.re) * 0.5f, (a.im - b0.im) * 0.5f};
+            const C<float> d = {(a.re - b0.re) * 0.5f, (a.im + b0.im) * 0.5f};
+            const C<float> o = {d.im, -d.re};
+            const C<float> wo = cmul(tw2n[k], o);
+            const C<float> xlo = {e.re + wo.re, e.im + wo.im}, xhi = {e.re - wo.re, wo.im - e.im};
+            mlo[i] = __builtin_amdgcn_sqrtf(xlo.re * xlo.re + xlo.im * xlo.im);
+            mhi[i] = __builtin_amdgcn_sqrtf(xhi.re * xhi.re + xhi.im * xhi.im);
+            // bin N (the partner of bin 0) belongs to the spectrum only when nbin = N + 1
+            part += mlo[i] + ((i == 0 && tl == 0 && nbin <= N) ? 0.f : mhi[i]);
+        }
+        const C<float> zmid = img[pad(N / 2)];
+        const float mmid = __builtin_amdgcn_sqrtf(zmid.re * zmid.re + zmid.im * zmid.im);
+        if (tl == 0) part += mmid;
+        float div = 1.f, mul = 1.f;
+        if (mode == 2) {
+            mul = 2.f;
+            div = scale;
+        }
+        // the two barriers of the sum also keep the next tile's results out of the image until
+        // every lane has read its bins
+        const float sum = frame_sum<NT>(part, scratch, 0, tl);
+        if (mode == 1 || (mode == 0 && sum > 0.00001f)) div = sum;
+        const float gain = mul * __builtin_amdgcn_rcpf(div);
+        const __amdgpu_buffer_rsrc_t dst = uniform_descriptor(ps + frame * nbin, (int)nbin * 4);
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const unsigned k = tl + NT * i;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mlo[i] * gain), dst, (int)k * 4, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mhi[i] * gain), dst, (int)(N - k) * 4, 0, 2);  // bin N: out of range when nbin = N
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mmid * gain), dst, tl == 0 ? (N / 2) * 4 : 0x7ffffff0, 0, 2);
+    }
+};
+
+constexpr size_t kSpectrumImageBytes = padded_len(2048) * sizeof(C<float>);
+constexpr size_t fir_spectrum_lds_bytes(int ns)
+{
+    return half_lds_bytes(ns) + kSpectrumImageBytes + lds_twiddle_entries(3, 8, 8, 8, 4, 2048) * sizeof(C<float>) + 4 * sizeof(float);
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void fir_spectrum_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale,
+                                                           const C<float> *__restrict__ tw, const C<float> *__restrict__ tw2n,
+                                                           float *ps, unsigned nbin, int mode, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr size_t kPlanes = half_lds_bytes(NS);
+    SpectrumSink<NS> sink;
+    sink.img = reinterpret_cast<C<float> *>(smem_raw + kPlanes);
+    setup_lds_twiddles_split<float, 2048, 256, 1, 8, 8, kPlanes + kSpectrumImageBytes>(smem_raw, tw, sink.tw1, sink.tw2, sink.tw3);
+    sink.tw = tw;
+    sink.tw2n = tw2n;
+    sink.scratch = reinterpret_cast<float *>(smem_raw + kPlanes + kSpectrumImageBytes +
+                                             lds_twiddle_entries(3, 8, 8, 8, 4, 2048) * sizeof(C<float>));
+    sink.ps = ps;
+    sink.nbin = nbin;
+    sink.frames_per_chan = p.tiles_per_chan;
+    sink.mode = mode;
+    sink.scale = scale;
+    sink.frame = 0;
+    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink);
+}
+
+template <int NS>
+int launch_fir_spectrum_t(const FirParams<float> &p, const dspmi::FirSpectrumLaunch &a, unsigned blocks, hipStream_t s)
+{
+    auto kern = fir_spectrum_kernel<NS>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), fir_spectrum_lds_bytes(NS), s, p, static_cast<const u32x4 *>(a.tap_images),
+                       a.tap_unscale, static_cast<const C<float> *>(a.tw_half), static_cast<const C<float> *>(a.tw_full), a.ps,
+                       a.nbin, a.mode, a.scale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1783,6 +1926,41 @@ const FftEntry *find_entry(unsigned n, int precision)
 }  // namespace
 
 namespace dspmi {
+
+int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s)
+{
+    FirParams<float> p{};
+    p.x = a.x;
+    p.hist = a.hist;
+    p.x_stride = a.x_stride;
+    p.hist_stride = a.hist_stride;
+    p.nxx = p.nx = a.nx;
+    p.nh = a.nh;
+    p.tiles_per_chan = a.nx / kSplitTile;
+    const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * a.nchan;
+    if (tiles == 0) return DSPMI_OK;
+    if (tiles > 0x7fffffffull) return fail(DSPMI_EINVAL, "fir_spectrum: %llu frames exceed the grid limit", tiles);
+    p.ntiles_total = (unsigned)tiles;
+    unsigned tpb = (unsigned)(tiles / 8192);
+    p.tiles_per_block = tpb < 2 ? (tiles >= 2048 ? 2 : 1) : (tpb > 16 ? 16 : tpb);
+    if (const char *env = getenv("DSPMI_FIR_TPB"))
+        if (atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
+    const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
+    switch (a.slices) {
+    case 1: return launch_fir_spectrum_t<1>(p, a, blocks, s);
+    case 2: return launch_fir_spectrum_t<2>(p, a, blocks, s);
+    case 3: return launch_fir_spectrum_t<3>(p, a, blocks, s);
+    case 4: return launch_fir_spectrum_t<4>(p, a, blocks, s);
+    case 5: return launch_fir_spectrum_t<5>(p, a, blocks, s);
+    case 6: return launch_fir_spectrum_t<6>(p, a, blocks, s);
+    case 7: return launch_fir_spectrum_t<7>(p, a, blocks, s);
+    case 8: return launch_fir_spectrum_t<8>(p, a, blocks, s);
+    case 9: return launch_fir_spectrum_t<9>(p, a, blocks, s);
+    case 10: return launch_fir_spectrum_t<10>(p, a, blocks, s);
+    }
+    return fail(DSPMI_EINVAL, "fir_spectrum: no kernel of %d slices", a.slices);
+}
+
 
 const FftKernel *fft_find(unsigned n, int precision) { return find_entry(n, precision); }
 

@@ -23,6 +23,7 @@
 // restates `convolve` (fir/src/main.c:258-280, fft/src/main.c:180-205) and
 // conv0/conv1 (convolution/main.c:15-53) of the reference; see dspmi.h.
 #include "common.h"
+#include "fir_half.h"
 
 #include <cstdint>
 #include <cstring>
@@ -30,19 +31,6 @@
 #include <vector>
 
 namespace {
-
-template <typename T>
-struct FirParams {
-    T *y;
-    const T *x;
-    const T *hist;
-    const T *taps;  // nhp values, zero-padded past nh
-    size_t y_stride, x_stride, hist_stride;
-    unsigned nxx, nx, nh, nhp;
-    unsigned tiles_per_chan;
-    unsigned flags;
-    unsigned ntiles_total, tiles_per_block;  // MFMA kernel: tiles over all channels / per workgroup
-};
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_type(4))); };
@@ -214,7 +202,6 @@ __global__ __launch_bounds__(256) void fir_direct_kernel(const FirParams<T> p)
 // f32 Toeplitz-MFMA kernel
 // ---------------------------------------------------------------------------
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int mfma_tile(int TPW) { return 4 * TPW * 256; }  // outputs per workgroup: 4 waves x TPW tiles x 256
 constexpr int kMfmaSeg = 2048;   // taps per LDS staging round
@@ -510,11 +497,8 @@ __global__ __launch_bounds__(256) void fir_mfma_kernel(const FirParams<float> p)
 // read, conflict-free on unpadded planes (lane groups of that read land on distinct 16-byte
 // slots for a 32-byte lane stride).  NS = 32-position slices of the window: NS*32 >= nh + 15.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kSplitTile = 4096;  // outputs per workgroup step: 4 waves x 4 blocks of 256
 constexpr int kSplitMaxSlices = 10;
 constexpr size_t split_lds_bytes(int ns) { return (size_t)2 * 3 * (kSplitTile + 32 * ns - 16) * 2; }  // two sets of three planes
 
@@ -750,268 +734,36 @@ __global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p
 }
 
 // ---------------------------------------------------------------------------
-// f32 FIR on the f16 matrix pipe: operands split two ways, one scale per tile
+// f32 FIR on the f16 matrix pipe (fir_half.h), results stored
 // ---------------------------------------------------------------------------
-//
-// The same tiling with half-precision parts.  A float scaled into [2^14, 2^15) is hi + lo + e
-// with hi = the value rounded to f16 (11 significant bits), lo = the remainder rounded, and
-// |e| <= 2^-23 of it; f16 reaches 2^-24 in absolute terms, so under one scale per tile -- the
-// power of two that brings the window's largest sample into that range -- a sample keeps this
-// relative accuracy down to 100 dB below the tile's peak, and below that the error stays
-// 2^-40 of the peak.  Taps are scaled and split the same way once, at plan creation.  Three
-// products are kept of the four (hi*hi, hi*lo, lo*hi; lo*lo is 2^-22 of the product), so a
-// slice costs three MFMAs instead of the six of the three-way bf16 split, two LDS planes
-// instead of three, and results are multiplied by the inverse scales on their way out.
-//
-// The scale of tile i+2 is found while tile i runs: its samples sit in the staging registers
-// (reissued during the first steps of the iteration, so that they have landed at its end),
-// every wave reduces its share to a maximum and leaves it in LDS ahead of the iteration's
-// barrier; the next iteration reads the four maxima, and splits the tile with that scale.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr size_t half_lds_bytes(int ns) { return (size_t)2 * 2 * (kSplitTile + 32 * ns - 16) * 2 + 64; }  // two sets of two planes + the maxima
-
-// f16(lo) in the low half, f16(hi) in the high half, both rounded to nearest even
-__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi)
-{
-    unsigned r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-
-// two floats, scaled -> their two f16 parts, packed pairwise; the subtractions are exact
-__device__ __forceinline__ void half_pair(float x0, float x1, float scale, unsigned &hi, unsigned &lo)
-{
-    const float s0 = x0 * scale, s1 = x1 * scale;
-    hi = cvt_pk_f16(s0, s1);
-    const f16x2 h = __builtin_bit_cast(f16x2, hi);
-    lo = cvt_pk_f16(s0 - (float)h[0], s1 - (float)h[1]);
-}
-
-// the largest value of a wave's lanes (non-negative inputs), returned in every lane
-__device__ __forceinline__ float wave_max(float v)
-{
-#define DSPMI_DPP_MAX(ctrl, row_mask) \
-    v = __builtin_fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false)))
-    DSPMI_DPP_MAX(0xb1, 0xf);    // quad_perm [1,0,3,2]
-    DSPMI_DPP_MAX(0x4e, 0xf);    // quad_perm [2,3,0,1]
-    DSPMI_DPP_MAX(0x141, 0xf);   // row_half_mirror
-    DSPMI_DPP_MAX(0x140, 0xf);   // row_mirror: every lane of a row of 16 holds the row's maximum
-    DSPMI_DPP_MAX(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
-    DSPMI_DPP_MAX(0x143, 0xc);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
-#undef DSPMI_DPP_MAX
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
+// Results leave through a descriptor over the tile's part of the row: the row's ragged end
+// needs no branch, and only 4-byte alignment.
+struct StoreSink {
+    static constexpr bool kTileHook = false;
+    const FirParams<float> &p;
+    __amdgpu_buffer_rsrc_t yrsrc;
+    __device__ __forceinline__ explicit StoreSink(const FirParams<float> &params) : p(params) {}
+    __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start)
+    {
+        const long left = (long)p.nxx - tile_start;
+        yrsrc = uniform_descriptor(p.y + (size_t)chan * p.y_stride + tile_start, (int)(left < kSplitTile ? left : kSplitTile) * 4);
+    }
+    __device__ __forceinline__ void emit(int q, f32x4 res)
+    {
+        const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int off = (int)(wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, res), yrsrc, off, 0, 2);  // nontemporal
+    }
+    __device__ __forceinline__ void end_tile() {}
+};
 
 template <int NS>
 __global__ __launch_bounds__(256) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
 {
-    constexpr int P = 32 * NS - 16;          // window positions ahead of a block's first output
-    constexpr int NSTAGE = kSplitTile + P;   // samples staged per tile (a multiple of 16)
-    constexpr int NQ = NSTAGE / 4;           // ... in groups of four
-    constexpr int NIT = (NQ + 255) / 256;    // groups per lane (the last one on a few lanes only)
-    constexpr int NSTEP = 4 * NS;            // MFMA steps per wave and tile
-    static_assert(P / 4 <= 256, "the history falls into every lane's first group");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    unsigned short *lds = reinterpret_cast<unsigned short *>(smem_raw);  // [2][2][NSTAGE]
-    float *maxima = reinterpret_cast<float *>(lds + 4 * NSTAGE);          // [2][4]: per tile parity, per wave
-
-    const unsigned t = threadIdx.x;
-    const unsigned lane = t & 63, wave = t >> 6;
-    const long nx = p.nx, nh = p.nh;
-
-    f16x8 hf[NS][2];
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++) hf[s][pl] = __builtin_bit_cast(f16x8, htab[(s * 2 + pl) * 64 + lane]);
-
-    const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
-    const long tile_hi = min(tile_lo + (long)p.tiles_per_block, (long)p.ntiles_total);
-    if (tile_hi <= tile_lo) return;
-    const long nunits = tile_hi - tile_lo;
-    unsigned cur_chan = (unsigned)(tile_lo / p.tiles_per_chan);
-    unsigned cur_tile = (unsigned)(tile_lo - (long)cur_chan * p.tiles_per_chan);
-
-    auto descriptor = [](const void *ptr, int bytes) {
-        const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        void *base = reinterpret_cast<void *>(((uintptr_t)hi << 32) | lo);
-        return __builtin_amdgcn_make_buffer_rsrc(base, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-    };
-
-    struct Unit {
-        const float *xbase, *hbase;  // first sample / first history sample the descriptors cover
-        int xbytes, hbytes;          // ... and how much (0: nothing to read)
-        int xoff, hoff;              // byte offset of the window's first sample from those
-        long tile_start;
-        unsigned chan;
-    };
-    long described = 0;
-    auto describe = [&]() {
-        Unit d;
-        const bool valid = described++ < nunits;  // a tile past this workgroup's last reads nothing
-        d.chan = valid ? cur_chan : 0;
-        d.tile_start = (long)cur_tile * kSplitTile;
-        if (++cur_tile == p.tiles_per_chan) {
-            cur_tile = 0;
-            ++cur_chan;
-        }
-        const long sbase = d.tile_start - P;          // the window is samples [sbase, sbase + NSTAGE)
-        const long lo = sbase < 0 ? 0 : sbase;
-        long n = min(nx, sbase + NSTAGE) - lo;
-        if (n < 0 || !valid) n = 0;
-        d.xbase = p.x + (size_t)d.chan * p.x_stride + lo;
-        d.xbytes = (int)n * 4;
-        d.xoff = (int)(sbase - lo) * 4;               // <= 0: an offset before the row is out of range
-        const bool hist = valid && p.hist && sbase < 0;
-        d.hbase = hist ? p.hist + (size_t)d.chan * p.hist_stride : p.x;
-        d.hbytes = hist ? (int)(nh - 1) * 4 : 0;
-        d.hoff = hist ? (int)(sbase + nh - 1) * 4 : 0;
-        return d;
-    };
-
-    f32x4 stage[NIT];
-    u32x4 hstage;  // the history's share of the first group (zero except in a row's first tile)
-    auto load_piece = [&](const Unit &d, int it) {
-        const unsigned u = t + 256 * it;
-        const int g = (int)(it < NIT - 1 || u < (unsigned)NQ ? u : (unsigned)NQ - 1) * 16;
-        const int xo = d.xoff + g;
-        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(descriptor(d.xbase, d.xbytes), xo < 0 ? 0x7ffffff0 : xo, 0, 0));
-        if (it == 0) {
-            const __amdgpu_buffer_rsrc_t hrsrc = descriptor(d.hbase, d.hbytes);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int ho = d.hoff + g + 4 * e;
-                hstage[e] = __builtin_amdgcn_raw_buffer_load_b32(hrsrc, ho < 0 ? 0x7ffffff0 : ho, 0, 0);
-            }
-        }
-    };
-    auto put_piece = [&](unsigned short *planes, int it, float scale) {
-        const unsigned u = t + 256 * it;
-        if (it < NIT - 1 || u < (unsigned)NQ) {
-            unsigned h0, l0, h1, l1;
-            half_pair(stage[it][0], stage[it][1], scale, h0, l0);
-            half_pair(stage[it][2], stage[it][3], scale, h1, l1);
-            *reinterpret_cast<u32x2 *>(planes + 4 * u) = (u32x2){h0, h1};
-            *reinterpret_cast<u32x2 *>(planes + NSTAGE + 4 * u) = (u32x2){l0, l1};
-        }
-    };
-    // once the staging registers have landed: the history joins the first group, and the wave's
-    // largest magnitude goes to LDS for the tile of this parity
-    auto publish_max = [&](long tile_index) {
-        stage[0] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, stage[0]) | hstage);
-        float m = 0.f;
-#pragma unroll
-        for (int it = 0; it < NIT; it++)
-            m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(stage[it][0]), __builtin_fabsf(stage[it][1])),
-                                                __builtin_fmaxf(__builtin_fabsf(stage[it][2]), __builtin_fabsf(stage[it][3]))), m);
-        m = wave_max(m);
-        if (lane == 0) maxima[(tile_index & 1) * 4 + wave] = m;
-    };
-    // the tile's scale, a power of two that brings its largest sample into [2^14, 2^15) (kept
-    // within 2^-100 .. 2^100), and the factor that takes a sum of scaled products back
-    auto scales = [&](long tile_index, float &scale, float &unscale) {
-        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(maxima + (tile_index & 1) * 4);
-        const float m = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
-        int e = 268 - (int)((__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)) >> 23) & 0xff);
-        e = e < 27 ? 27 : (e > 227 ? 227 : e);
-        scale = __builtin_bit_cast(float, e << 23);
-        unscale = __builtin_bit_cast(float, (254 - e) << 23) * tap_unscale;
-    };
-
-    // B operand: lane holds column a = lane&15 (block a of 16 outputs), window positions
-    // 8*(lane>>4) .. +7 of each slice
-    const unsigned b_base = wave * 1024 + 16 * (lane & 15) + 8 * (lane >> 4);
-
-    // prologue: the first tile is split with nothing to overlap it, the second is on its way
-    Unit cur = describe();
-#pragma unroll
-    for (int it = 0; it < NIT; it++) load_piece(cur, it);
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++) asm volatile("" : "+v"(hf[s][pl]));  // landed before the loop (see fir_split_kernel)
-    publish_max(0);
-    __syncthreads();
-    float scale_nxt, unscale_cur, unscale_nxt;
-    scales(0, scale_nxt, unscale_cur);
-#pragma unroll
-    for (int it = 0; it < NIT; it++) put_piece(lds, it, scale_nxt);
-    Unit nxt = describe();
-#pragma unroll
-    for (int it = 0; it < NIT; it++) load_piece(nxt, it);
-    publish_max(1);
-    __syncthreads();
-
-    // One tile: its MFMAs out of one set of planes; in its first steps the next tile's split into
-    // the other set and the loads of the tile after it; at its end that tile's maximum.  A step =
-    // one slice of one block of 256 outputs: two 16-byte reads, three MFMAs (48 cycles); reads run
-    // two steps ahead.  The leading products go to one accumulator and the two corrections to
-    // another: the small terms then round against each other, not against the running sum.
-    auto iteration = [&](long unit) {
-        const unsigned short *rd_planes = lds + (unit & 1) * (2 * NSTAGE);
-        unsigned short *wr_planes = lds + ((unit & 1) ^ 1) * (2 * NSTAGE);
-        const Unit nxt2 = describe();
-        scales(unit + 1, scale_nxt, unscale_nxt);
-        const long left = (long)p.nxx - cur.tile_start;
-        const __amdgpu_buffer_rsrc_t yrsrc = descriptor(p.y + (size_t)cur.chan * p.y_stride + cur.tile_start,
-                                                        (int)(left < kSplitTile ? left : kSplitTile) * 4);
-        f16x8 xf[3][2];
-        f32x4 big[4], small[4];
-        const unsigned short *xp = rd_planes + b_base;
-        auto rd = [&](int step) {
-            const int off = 256 * (step / NS) + 32 * (step % NS);
-#pragma unroll
-            for (int pl = 0; pl < 2; pl++)
-                xf[step % 3][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(xp + pl * NSTAGE + off));
-        };
-        auto store = [&](int q) {
-            u32x4 res;
-#pragma unroll
-            for (int r = 0; r < 4; r++) res[r] = __builtin_bit_cast(unsigned, (big[q][r] + small[q][r]) * unscale_cur);
-            const int off = (int)(wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) * 4;
-            __builtin_amdgcn_raw_buffer_store_b128(res, yrsrc, off, 0, 2);  // nontemporal
-        };
-        rd(0);
-        if (NSTEP > 1) rd(1);
-        int piece = 0;
-#pragma unroll
-        for (int step = 0; step < NSTEP; step++) {
-            const int q = step / NS, s = step % NS, slot = step % 3;
-            if (step + 2 < NSTEP) rd(step + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            f32x4 sm = s ? small[q] : zero, bg = s ? big[q] : zero;
-            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][0], xf[slot][1], sm, 0, 0, 0);
-            bg = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][0], xf[slot][0], bg, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][1], xf[slot][0], sm, 0, 0, 0);
-            small[q] = sm;
-            big[q] = bg;
-            // one piece per step from the first step on (all of them at once where a tile has
-            // fewer steps than pieces): the earlier a register is reloaded, the surer it has
-            // landed when the iteration ends
-#pragma unroll
-            for (; piece < NIT && (piece <= step || step == NSTEP - 1); piece++) {
-                put_piece(wr_planes, piece, scale_nxt);
-                load_piece(nxt2, piece);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == 0 && q > 0) store(q - 1);
-        }
-        store(3);
-        if (unit + 1 < nunits) {
-            publish_max(unit + 2);
-            __syncthreads();  // the other planes and the maxima are complete, and every wave has left these planes
-        }
-        cur = nxt;
-        nxt = nxt2;
-        unscale_cur = unscale_nxt;
-    };
-    iteration(0);  // a copy of the loop body, so that the loop is entered with its own order of memory operations
-    for (long unit = 1; unit < nunits; unit++) iteration(unit);
+    StoreSink sink(p);
+    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink);
 }
 
 }  // namespace
@@ -1465,6 +1217,23 @@ int dspmi_fir_exec_f64_desc(dspmi_fir_t plan, double *y, size_t y_stride, unsign
 {
     return exec<double>(plan, y, y_stride, nxx, x, x_stride, nx, nchan, nullptr, 0, flags, stream, DSPMI_F64, true);
 }
+
+namespace dspmi {
+
+int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *slices, unsigned *nh, int *device)
+{
+    if (!plan) return fail(DSPMI_EINVAL, "null FIR plan");
+    if (!plan->half_tab)
+        return fail(DSPMI_ENOSYS, "the FIR plan runs %s, not the f16 matrix kernel (40..305 taps, or DSPMI_FIR_VARIANT=f16)", plan->name);
+    *images = plan->half_tab;
+    *unscale = plan->half_unscale;
+    *slices = plan->split_ns;
+    *nh = plan->nh;
+    *device = plan->device;
+    return DSPMI_OK;
+}
+
+}  // namespace dspmi
 
 extern "C" {
 

@@ -60,6 +60,7 @@ _SIGS = {
     "dspmi_ols_fft_length": (_u, [_vp]),
     "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
     "dspmi_fft_exec_r2c_spectrum": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
+    "dspmi_fir_spectrum_f32": (C.c_int, [_vp, _vp, _vp, _u, C.c_int, C.c_float, _vp, _sz, _u, _u, _vp, _sz, _vp]),
     "dspmi_fft_exec_r2c_spectrum_s16x2": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
     "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
@@ -166,6 +167,26 @@ class FirPlan:
         _check(fn(self._h, y.data_ptr(), y.stride(0) if nchan > 1 else nxx, nxx,
                   x.data_ptr(), x.stride(0) if nchan > 1 else nx, nx, nchan, hp, hs, flags, _stream()), "fir_exec")
         return y
+
+    def spectrum(self, fft, x, hist=None, nbin=None, mode=0, scale=1.0, out=None):
+        """Filter, then the normalised magnitude spectrum of every 4096 filtered samples, in one
+        kernel (the filtered samples are never written): x [nchan, nx], nx a multiple of 4096,
+        fft an f32 FftPlan(4096) -> [nchan * nx / 4096, nbin].  Plans of 40..305 taps only."""
+        import torch
+        assert not self.f64 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        nchan, nx = x.shape
+        if nbin is None:
+            nbin = fft.n // 2 + 1
+        if out is None:
+            out = torch.empty((nchan * (nx // fft.n), nbin), dtype=torch.float32, device=x.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == nchan * (nx // fft.n) * nbin
+        hp, hs = None, 0
+        if hist is not None:
+            assert hist.is_cuda and hist.dtype == torch.float32 and hist.shape == (nchan, self.nh - 1) and hist.stride(1) == 1
+            hp, hs = hist.data_ptr(), hist.stride(0) if nchan > 1 else self.nh - 1
+        _check(lib().dspmi_fir_spectrum_f32(self._h, fft._h, out.data_ptr(), nbin, mode, scale, x.data_ptr(),
+                                            x.stride(0) if nchan > 1 else nx, nx, nchan, hp, hs, _stream()), "fir_spectrum")
+        return out
 
     def exec_s16x2(self, frames, out=None):
         """frames: [nblock, nsampl, 2] int16 CUDA tensor of stereo capture blocks; every block is

@@ -261,6 +261,18 @@ int dspmi_fft_exec_r2c_spectrum(dspmi_fft_t plan, const void *in, float *ps, siz
 int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float *ps, size_t batch,
                                       unsigned nbin, int mode, float scale, void *stream);
 
+/* The filter and spectrum stages of the capture loop in one pass (alsa/main.c:542-568: do_fir,
+ * then do_power_spectrum on the filtered samples), for callers that want the spectra only:
+ * ps[c * (nx / 4096) + f][k], k < nbin, is the normalised magnitude spectrum (mode, scale as
+ * above; nbin = 2048 or 2049) of filtered samples 4096 f .. 4096 f + 4095 of channel c, the
+ * filtered samples being those of dspmi_fir_exec_f32(fir, ..., nxx = nx, hist) -- they are never
+ * written to memory.  fir: an f32 plan that runs the f16 matrix kernel (40 .. 305 taps); fft:
+ * an f32 plan of 4096 points; nx a multiple of 4096.  DSPMI_ENOSYS for any other pair of plans:
+ * the caller then makes the two calls. */
+int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode,
+                           float scale, const float *x, size_t x_stride, unsigned nx, unsigned nchan,
+                           const float *hist, size_t hist_stride, void *stream);
+
 /* Tone generator of tonegen/tonegen.c:25-40 on the device, one generator per channel:
  * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from

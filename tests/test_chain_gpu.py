@@ -243,3 +243,83 @@ def test_tonegen_complex_output_feeds_the_c2c_transform():
     spec = dsp_amd.FftPlan(n, "f32").c2c(z).cpu().numpy()
     peaks = np.argsort(-np.abs(spec[0][: n // 2]))[:3]
     assert sorted(peaks) == [20, 40, 60]                  # 2, 4, 6 kHz at 100 Hz per bin
+
+
+@pytest.mark.parametrize("nh", [40, 64, 127, 200, 305])
+def test_fir_and_spectrum_in_one_kernel(nh):
+    """dspmi_fir_spectrum_f32 against the oracle run stage by stage in double (filter from the
+    carried history, then |rfft| / sum of every 4096 filtered samples) and against the two
+    device calls it replaces; every normalisation mode, with and without the Nyquist bin, rows
+    of several frames, a frame whose sum stays under the 1e-5 guard."""
+    rng = np.random.default_rng(nh)
+    nchan, nfft, frames = 7, 4096, 3
+    nx = nfft * frames
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    fir = dsp_amd.FirPlan(h, "f32")
+    assert "f16x2" in fir.variant
+    fft = dsp_amd.FftPlan(nfft, "f32")
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    x[2] *= 1e-9                                   # spectra below the guard: left un-normalised in mode 0
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    hist[2] *= 1e-9
+    xd, hd = torch.from_numpy(x).cuda(), torch.from_numpy(hist).cuda()
+    want_y = oracle.fir_batch_f32(np.concatenate([hist, x], axis=1), h, nh - 1 + nx)[:, nh - 1:]
+    y = fir.exec(xd, nx, hist=hd)
+    for nbin, mode, scale in ((2049, dsp_amd.PS_NORM_GUARDED, 1.0), (2048, dsp_amd.PS_NORM, 1.0), (2048, dsp_amd.PS_ABS, float(nfft)),
+                              (2049, dsp_amd.PS_ABS, 3.0)):
+        got = fir.spectrum(fft, xd, hist=hd, nbin=nbin, mode=mode, scale=scale).cpu().numpy()
+        two = fft.r2c_spectrum(y.view(-1, nfft), nbin=nbin, mode=mode, scale=scale).cpu().numpy()
+        assert got.shape == (nchan * frames, nbin)
+        for c in range(nchan):
+            for f in range(frames):
+                bins = oracle.fft_r2c(want_y[c, f * nfft:(f + 1) * nfft])
+                mag = np.abs(bins[:nbin])
+                if mode == dsp_amd.PS_ABS:
+                    want = 2 * mag / scale
+                elif mode == dsp_amd.PS_NORM or mag.sum() > 1e-5:
+                    want = mag / mag.sum()
+                else:
+                    want = mag
+                assert rel_l2(got[c * frames + f], want) <= 1e-5, (nh, nbin, mode, c, f)
+                assert rel_l2(got[c * frames + f], two[c * frames + f]) <= 1e-5, (nh, nbin, mode, c, f)
+    # without history every row starts from zero state
+    got = fir.spectrum(fft, xd).cpu().numpy()
+    two = fft.r2c_spectrum(fir.exec(xd, nx).view(-1, nfft)).cpu().numpy()
+    for i in range(nchan * frames):
+        assert rel_l2(got[i], two[i]) <= 1e-5, i
+
+
+def test_fir_and_spectrum_walks_many_frames():
+    """Enough frames that every workgroup walks several (the steady state of the tile pipeline,
+    with the frame image reused tile after tile), rows of one frame and of many; the two device
+    calls as reference, spot frames against the oracle."""
+    nh, nfft = 127, 4096
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    fir, fft = dsp_amd.FirPlan(h, "f32"), dsp_amd.FftPlan(nfft, "f32")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for nchan, frames in ((3000, 1), (96, 40)):
+        x = torch.rand((nchan, frames * nfft), device="cuda", generator=g) * 2 - 1
+        hist = torch.rand((nchan, nh - 1), device="cuda", generator=g) * 2 - 1
+        got = fir.spectrum(fft, x, hist=hist, nbin=2048, mode=dsp_amd.PS_NORM)
+        two = fft.r2c_spectrum(fir.exec(x, hist=hist).view(-1, nfft), nbin=2048, mode=dsp_amd.PS_NORM)
+        err = ((got - two).double().norm(dim=1) / two.double().norm(dim=1)).max().item()
+        assert err <= 1e-5, (nchan, frames, err)
+        assert abs(got.sum(dim=1) - 1).max().item() < 1e-4
+        for c, f in ((0, 0), (nchan - 1, frames - 1), (nchan // 2, frames // 2)):
+            lo = f * nfft
+            seg = torch.cat([hist[c], x[c]])[lo:lo + nfft + nh - 1].cpu().numpy()
+            yy = oracle.fir_batch_f32(seg[None, :], h, len(seg))[0][nh - 1:]
+            mag = np.abs(oracle.fft_r2c(yy)[:2048])
+            assert rel_l2(got[c * frames + f].cpu().numpy(), mag / mag.sum()) <= 1e-5, (c, f)
+
+
+def test_fir_and_spectrum_refuses_what_it_cannot_run():
+    fft = dsp_amd.FftPlan(4096, "f32")
+    x = torch.zeros((2, 8192), device="cuda")
+    with pytest.raises(dsp_amd.DspmiError, match="f16"):
+        dsp_amd.FirPlan(oracle.TAPS16.astype(np.float32), "f32").spectrum(fft, x)          # 16 taps: the f32 kernel
+    fir = dsp_amd.FirPlan(oracle.windowed_sinc_taps(127).astype(np.float32), "f32")
+    with pytest.raises(dsp_amd.DspmiError, match="4096"):
+        fir.spectrum(dsp_amd.FftPlan(2048, "f32"), x)
+    with pytest.raises(dsp_amd.DspmiError, match="whole frames"):
+        fir.spectrum(fft, torch.zeros((2, 5000), device="cuda"), out=torch.zeros((2, 2049), device="cuda"))
