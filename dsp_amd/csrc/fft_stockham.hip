@@ -729,19 +729,90 @@ struct SpectrumSink {
         img[pad(j)] = {res[0], res[1]};
         img[pad(j) + 1] = {res[2], res[3]};
     }
+    // The transform is run_passes<float, 2048, 256, 8, 8, 8, 4> written out: with N and the
+    // radices fixed, every LDS address of a pass is one lane-dependent base plus a constant
+    // (pad(i + c) = pad(i) + 17 c / 16 for c a multiple of 16, and the pass-1 / pass-2 write
+    // patterns by inspection), which the generic index arithmetic -- four vector instructions per
+    // address, 260 per tile -- does not reveal to the compiler; and the twiddles of the two long
+    // passes are powers of one table product instead of seven.
     __device__ __forceinline__ void end_tile()
     {
         unsigned tl = threadIdx.x;
-        asm volatile("" : "+v"(tl));  // keeps the addresses below out of the walker's loop-invariant registers
+        asm volatile("" : "+v"(tl));  // keeps the bases below out of the walker's loop-invariant registers
+        const unsigned rb = tl + (tl >> 4);                       // pad(tl)
+        const unsigned w1 = 8 * tl + (tl >> 1);                   // pad(8 tl)
+        const unsigned j2 = ((tl >> 3) << 6) + (tl & 7), w2 = j2 + (j2 >> 4);
+        const unsigned j3 = ((tl >> 6) << 9) + (tl & 63), w3 = j3 + (j3 >> 4);
+        const unsigned pb = (256 - tl) + ((256 - tl) >> 4);       // pad(256 - tl)
+        const C<float> *ta = tw2, *tb = tw2 + N / 64;              // W^(64 a), W^b
         C<float> v[P];
 #pragma unroll
-        for (int r = 0; r < R0; r++) v[r] = img[pad(tl + r * (N / R0))];
+        for (int r = 0; r < 8; r++) v[r] = img[rb + 272 * r];    // points tl + 256 r
         __syncthreads();  // every lane holds its inputs before the first pass writes the image
-        run_passes<float, N, NT, R0, R1, R2, R3, TW>(v, img, tw1, tw2, tw3, tw, pass_lane<TW>(tl));
+
+        // pass 1: radix 8 over stride 256; butterfly tl writes 8 tl + r
+        dft_reg<8, 1>(v);
 #pragma unroll
-        for (int b = 0; b < P / R3; b++)
+        for (int r = 0; r < 8; r++) img[w1 + r] = v[r];
+        __syncthreads();
+
+        // pass 2: radix 8, 8 sub-transforms interleaved; twiddles W^(32 k r), k = tl mod 8, from their table
 #pragma unroll
-            for (int r = 0; r < R3; r++) img[pad(tl + NT * b + r * (N / R3))] = v[b * R3 + r];
+        for (int r = 0; r < 8; r++) v[r] = img[rb + 272 * r];
+        __syncthreads();
+        {
+            const C<float> *t = tw1 + (tl & 7);
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], t[(r - 1) * 8]);
+        }
+        dft_reg<8, 1>(v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) img[w2 + 8 * r + (r >> 1)] = v[r];  // pad(j2 + 8 r)
+        __syncthreads();
+
+        // pass 3: radix 8, 64 interleaved; twiddles W^(4 k r), k = tl mod 64, as powers of W^(4k)
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = img[rb + 272 * r];
+        __syncthreads();
+        {
+            const unsigned e = 4 * (tl & 63);
+            const C<float> p1 = cmul(ta[e >> 6], tb[e & 63]);
+            const C<float> p2 = cmul(p1, p1), p3 = cmul(p2, p1), p4 = cmul(p2, p2);
+            v[1] = cmul(v[1], p1);
+            v[2] = cmul(v[2], p2);
+            v[3] = cmul(v[3], p3);
+            v[4] = cmul(v[4], p4);
+            v[5] = cmul(v[5], cmul(p4, p1));
+            v[6] = cmul(v[6], cmul(p3, p3));
+            v[7] = cmul(v[7], cmul(p4, p3));
+        }
+        dft_reg<8, 1>(v);
+#pragma unroll
+        for (int r = 0; r < 8; r++) img[w3 + 68 * r] = v[r];     // pad(j3 + 64 r)
+        __syncthreads();
+
+        // pass 4: radix 4, two butterflies per lane (j = tl, tl + 256); twiddles W^(j r)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[4 * b + r] = img[rb + 272 * b + 544 * r];  // points j + 512 r
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const unsigned e = tl + 256 * b;
+            const C<float> p1 = cmul(ta[e >> 6], tb[e & 63]);
+            const C<float> p2 = cmul(p1, p1);
+            v[4 * b + 1] = cmul(v[4 * b + 1], p1);
+            v[4 * b + 2] = cmul(v[4 * b + 2], p2);
+            v[4 * b + 3] = cmul(v[4 * b + 3], cmul(p2, p1));
+            dft_reg<4, 1>(&v[4 * b]);
+        }
+        // park Z in natural order; Z[0] once more in the spare slot, where bin 0 looks for Z[N]
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) img[rb + 272 * b + 544 * r] = v[4 * b + r];
+        if (tl == 0) img[pad(N)] = v[0];
         __syncthreads();
 
         // bins in pairs, as in fft_r2c_kernel: X[k] = E[k] + W^k O[k], X[N-k] = conj(E[k] - W^k O[k])
@@ -751,8 +822,8 @@ struct SpectrumSink {
 #pragma unroll
         for (int i = 0; i < H; i++) {
             const unsigned k = tl + NT * i;
-            const C<float> a = img[pad(k)];
-            const C<float> b0 = img[pad((N - k) & (N - 1))];
+            const C<float> a = img[rb + 272 * i];
+            const C<float> b0 = img[pb + 1904 - 272 * i];         // pad(N - k); the spare slot for k = 0
             const C<float> e = {(a.re + b0.re) * 0.5f, (a.im - b0.im) * 0.5f};
             const C<float> d = {(a.re - b0.re) * 0.5f, (a.im + b0.im) * 0.5f};
             const C<float> o = {d.im, -d.re};

@@ -82,11 +82,16 @@ __device__ __forceinline__ void half_pair(float x0, float x1, float scale, unsig
     lo = cvt_pk_f16(s0 - (float)h[0], s1 - (float)h[1]);
 }
 
-// the largest value of a wave's lanes (non-negative inputs), returned in every lane
-__device__ __forceinline__ float wave_max(float v)
+// The largest of a wave's values, returned in every lane.  The values are magnitudes of floats as
+// bit patterns (sign bit cleared), which order like the floats they stand for: integer maxima
+// need none of the canonicalising instructions a float maximum brings with it.
+__device__ __forceinline__ unsigned wave_max(unsigned v)
 {
-#define DSPMI_DPP_MAX(ctrl, row_mask) \
-    v = __builtin_fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false)))
+#define DSPMI_DPP_MAX(ctrl, row_mask)                                                                        \
+    {                                                                                                        \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xf, false);     \
+        v = v > o ? v : o;                                                                                   \
+    }
     DSPMI_DPP_MAX(0xb1, 0xf);    // quad_perm [1,0,3,2]
     DSPMI_DPP_MAX(0x4e, 0xf);    // quad_perm [2,3,0,1]
     DSPMI_DPP_MAX(0x141, 0xf);   // row_half_mirror
@@ -94,7 +99,7 @@ __device__ __forceinline__ float wave_max(float v)
     DSPMI_DPP_MAX(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
     DSPMI_DPP_MAX(0x143, 0xc);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum
 #undef DSPMI_DPP_MAX
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Sink: what becomes of the results.  begin_tile(channel, first output of the tile) is called
@@ -114,7 +119,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     constexpr int NSTEP = 4 * NS;            // MFMA steps per wave and tile
     static_assert(P / 4 <= 256, "the history falls into every lane's first group");
     unsigned short *lds = reinterpret_cast<unsigned short *>(smem_raw);  // [2][2][NSTAGE]
-    float *maxima = reinterpret_cast<float *>(lds + 4 * NSTAGE);          // [2][4]: per tile parity, per wave
+    unsigned *maxima = reinterpret_cast<unsigned *>(lds + 4 * NSTAGE);    // [2][4]: per tile parity, per wave; magnitudes as bit patterns
 
     const unsigned t = threadIdx.x;
     const unsigned lane = t & 63, wave = t >> 6;
@@ -196,20 +201,24 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     // largest magnitude goes to LDS for the tile of this parity
     auto publish_max = [&](long tile_index) {
         stage[0] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, stage[0]) | hstage);
-        float m = 0.f;
+        unsigned m = 0;
 #pragma unroll
-        for (int it = 0; it < NIT; it++)
-            m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(stage[it][0]), __builtin_fabsf(stage[it][1])),
-                                                __builtin_fmaxf(__builtin_fabsf(stage[it][2]), __builtin_fabsf(stage[it][3]))), m);
+        for (int it = 0; it < NIT; it++) {
+            const u32x4 b = __builtin_bit_cast(u32x4, stage[it]) & 0x7fffffffu;
+            const unsigned m01 = b[0] > b[1] ? b[0] : b[1], m23 = b[2] > b[3] ? b[2] : b[3];
+            const unsigned m4 = m01 > m23 ? m01 : m23;
+            m = m > m4 ? m : m4;
+        }
         m = wave_max(m);
         if (lane == 0) maxima[(tile_index & 1) * 4 + wave] = m;
     };
     // the tile's scale, a power of two that brings its largest sample into [2^14, 2^15) (kept
     // within 2^-100 .. 2^100), and the factor that takes a sum of scaled products back
     auto scales = [&](long tile_index, float &scale, float &unscale) {
-        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(maxima + (tile_index & 1) * 4);
-        const float m = __builtin_fmaxf(__builtin_fmaxf(m4[0], m4[1]), __builtin_fmaxf(m4[2], m4[3]));
-        int e = 268 - (int)((__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)) >> 23) & 0xff);
+        const u32x4 m4 = *reinterpret_cast<const u32x4 *>(maxima + (tile_index & 1) * 4);
+        const unsigned m01 = m4[0] > m4[1] ? m4[0] : m4[1], m23 = m4[2] > m4[3] ? m4[2] : m4[3];
+        const unsigned m = m01 > m23 ? m01 : m23;
+        int e = 268 - (int)((__builtin_amdgcn_readfirstlane((int)m) >> 23) & 0xff);
         e = e < 27 ? 27 : (e > 227 ? 227 : e);
         scale = __builtin_bit_cast(float, e << 23);
         unscale = __builtin_bit_cast(float, (254 - e) << 23) * tap_unscale;
