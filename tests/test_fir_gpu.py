@@ -451,3 +451,27 @@ def test_split_kernel_wide_dynamic_range(monkeypatch, split_kind):
     want = oracle.fir_batch_f32(xs, h, nx)
     for c in range(2):
         assert max(block_errors(got[c], want[c])) <= TOL_FIR
+
+
+def test_split_kernels_degenerate_shapes(monkeypatch, split_kind):
+    """No input at all, fewer samples than taps, one output, many one-tile rows: through the ABI."""
+    import ctypes as C
+    L = dsp_amd.lib()
+    nh = 64
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = split_plan(h, monkeypatch, split_kind)
+    y0 = torch.full((2, 9), 7.0, device="cuda")
+    assert L.dspmi_fir_exec_f32(plan._h, y0.data_ptr(), 9, 9, None, 0, 0, 2, None, 0, 0, None) == 0     # nx = 0: empty sums
+    torch.cuda.synchronize()
+    assert not y0.cpu().numpy().any()
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (4000, 5)).astype(np.float32)                                                 # 4000 rows of 5 samples
+    got = plan.exec(torch.from_numpy(x).cuda(), 5 + nh).cpu().numpy()
+    want = oracle.fir_batch_f32(x, h, 5 + nh)
+    for c in (0, 1, 1999, 3999):
+        assert_blocks(got[c], want[c], h, x[c], c)
+    hist = rng.uniform(-1, 1, (4000, nh - 1)).astype(np.float32)
+    got = plan.exec(torch.from_numpy(x).cuda(), 5, hist=torch.from_numpy(hist).cuda()).cpu().numpy()      # everything from the history
+    want = oracle.fir_batch_f32(np.concatenate([hist, x], axis=1), h, nh - 1 + 5)[:, nh - 1:]
+    for c in (0, 1, 1999, 3999):
+        assert_blocks(got[c], want[c], h, np.concatenate([hist[c], x[c]]), c)
