@@ -46,11 +46,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_descriptor(const void 
 // f32 FIR on the f16 matrix pipe: operands split two ways, one scale per tile
 // ---------------------------------------------------------------------------
 //
-// The same tiling with half-precision parts.  A float scaled into [2^14, 2^15) is hi + lo + e
+// The Toeplitz tiling of fir_split_kernel (fir_direct.hip: tap matrix as the A operand in
+// registers, windows of 16-output blocks as B operand columns read from LDS planes, tiles of 4096
+// outputs per workgroup step, next tile split while this one multiplies) with half-precision
+// parts.  A float scaled into [2^14, 2^15) is hi + lo + e
 // with hi = the value rounded to f16 (11 significant bits), lo = the remainder rounded, and
 // |e| <= 2^-23 of it; f16 reaches 2^-24 in absolute terms, so under one scale per tile -- the
 // power of two that brings the window's largest sample into that range -- a sample keeps this
-// relative accuracy down to 100 dB below the tile's peak, and below that the error stays
+// relative accuracy down to about 105 dB below the tile's peak, and below that the error stays
 // 2^-40 of the peak.  Taps are scaled and split the same way once, at plan creation.  Three
 // products are kept of the four (hi*hi, hi*lo, lo*hi; lo*lo is 2^-22 of the product), so a
 // slice costs three MFMAs instead of the six of the three-way bf16 split, two LDS planes
@@ -106,8 +109,10 @@ __device__ __forceinline__ unsigned wave_max(unsigned v)
 // by every lane before a tile's first block, emit(q, res) with a lane's four consecutive results
 // of block q (outputs tile + 1024 wave + 256 q + 16 (lane & 15) + 4 (lane >> 4) .. +3), and, where
 // Sink::kTileHook is set, end_tile() after a workgroup barrier that follows the tile's last emit
-// (the hook may use barriers itself; memory instructions in a sink must be unconditional, see
-// fir_split_kernel).  kExtraLds bytes of LDS behind the planes belong to the sink.
+// (the hook may use barriers itself).  Memory instructions in a sink must be unconditional: the
+// compiler's waits for the staging registers count the operations issued after each load, and
+// one load or store under a branch makes it wait for nearly everything (see fir_split_kernel).
+// LDS behind half_lds_bytes(NS) belongs to the sink.
 template <int NS, class Sink>
 __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const u32x4 *__restrict__ htab, float tap_unscale,
                                                char *smem_raw, Sink &sink)
