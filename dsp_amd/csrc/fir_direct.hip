@@ -779,8 +779,9 @@ struct dspmi_fir_plan {
     void *taps_dev;
     int variant;  // index into the table below
     std::vector<double> taps_host;
-    // f32 plans with enough taps also hold an overlap-save plan: the same outputs through
-    // FFTs cost fewer flops than 2*nh per sample and run faster from about 64 taps (doc/notes:81-82)
+    // f32 plans beyond the 16-bit kernels' tap counts also hold an overlap-save plan: the same
+    // outputs through FFTs cost fewer flops than 2*nh per sample (doc/notes:81-82) and beat the f32
+    // kernel from about 64 taps, the f16 kernel from about 310
     dspmi_ols_t ols = nullptr;
     unsigned ols_n = 0;
     // f32 plans of up to 32 * kSplitMaxSlices - 15 taps: the tap matrix of the bf16 kernel, as

@@ -26,9 +26,9 @@
  * concurrently.  One plan must not be executed from two threads (or on two
  * streams) at once: FFT and overlap-save plans own scratch buffers that an
  * execute may grow and that consecutive kernels of one execute share -- and an
- * f32 FIR plan of 64 taps or more owns an overlap-save plan, so the same rule
- * holds for it.  Only FIR plans without one (f64 plans, f32 plans of fewer than 64
- * taps or created with DSPMI_FIR_VARIANT=mfma / valu) hold nothing but their taps
+ * f32 FIR plan of 306 taps or more (or created with DSPMI_FIR_VARIANT=ols) owns
+ * an overlap-save plan, so the same rule holds for it.  FIR plans without one
+ * (f64 plans, f32 plans of up to 305 taps) hold nothing but their taps
  * and may be shared freely.  Every execute is asynchronous on the stream given;
  * destroying a plan while its work is still queued is the caller's error, as with
  * fftw_destroy_plan.
