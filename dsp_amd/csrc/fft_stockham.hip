@@ -323,6 +323,59 @@ __device__ __forceinline__ void run_passes(C<T> *v, C<T> *lds, const C<T> *tw1, 
     if constexpr (R3 > 1) fft_pass<T, N, NT, R3, NS3, false, NPASS == 4, TW>(v, lds, tw3, tw, tl);
 }
 
+// run_passes<float, 1024, 64, 16, 4, 16, 1, 2> -- a 1024-point frame inside one wave, sixteen
+// points per lane, full twiddle tables in LDS -- with the LDS addresses written as a few lane
+// bases plus compile-time constants (pad(i + c) = pad(i) + 17 c / 16 for c a multiple of 16),
+// so every access is a base register and an immediate offset.  The generic passes form each of
+// the 64 frame addresses and 18 table addresses with three or four integer instructions; here
+// the transform costs about ten.  Same arithmetic in the same order, so the same bits.
+__device__ __forceinline__ void row_passes_1024(C<float> *v, C<float> *lds, const C<float> *tw1, const C<float> *tw2,
+                                                unsigned tl)
+{
+    const unsigned rb = tl + (tl >> 4);                // pad(tl)
+    const unsigned w1 = 17 * tl;                       // pad(16 tl)
+    const unsigned w2 = 68 * (tl >> 4) + (tl & 15);    // pad(64 (tl / 16) + tl % 16)
+    // pass 1: radix 16 across the sixteen points 64 apart; butterfly tl writes 16 tl + r
+    dft_reg<16, 1>(v);
+#pragma unroll
+    for (int r = 0; r < 16; r++) lds[w1 + r] = v[r];
+    frame_sync<64>();
+    // pass 2: radix 4 over sixteen interleaved sub-transforms; butterflies tl + 64 b, all with
+    // the same twiddles (64 b is a multiple of 16)
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[4 * b + r] = lds[rb + 68 * b + 272 * r];
+    frame_sync<64>();
+    {
+        const C<float> *t = tw1 + (tl & 15);
+        const C<float> wa = t[0], wb = t[16], wc = t[32];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            v[4 * b + 1] = cmul(v[4 * b + 1], wa);
+            v[4 * b + 2] = cmul(v[4 * b + 2], wb);
+            v[4 * b + 3] = cmul(v[4 * b + 3], wc);
+            dft_reg<4, 1>(&v[4 * b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds[w2 + 272 * b + 17 * r] = v[4 * b + r];
+    frame_sync<64>();
+    // pass 3: radix 16 over 64 interleaved sub-transforms; results stay in registers, output r
+    // of butterfly tl at position tl + 64 r
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = lds[rb + 68 * r];
+    frame_sync<64>();
+    {
+        const C<float> *t = tw2 + tl;
+#pragma unroll
+        for (int r = 1; r < 16; r++) v[r] = cmul(v[r], t[64 * (r - 1)]);
+    }
+    dft_reg<16, 1>(v);
+}
+
 template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
 
 // Workgroups to launch for `nfb` frame-blocks when `resident` fit the chip at once.  A grid of
@@ -1286,7 +1339,7 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             // for every row and frame, and would otherwise be computed once and kept (spilled)
             unsigned la = lane, lh = lane, lb = lane;
             asm volatile("" : "+v"(la));
-            run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, la);
+            row_passes_1024(u[s], wreg, tw1, tw2, la);
             // spectrum times H (stored row by row: H[k1 + K1 k2] at [k1][k2]), real and imaginary
             // parts swapped for the second transform (backward = swap . forward . swap).
             // Requesting H before the transform would hide its latency but does not fit the 128
@@ -1300,7 +1353,7 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             }
             // ---- second transform: rows, stage factors, radix-K1 sum ----
             asm volatile("" : "+v"(lb));
-            run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw_sub, lb);
+            row_passes_1024(u[s], wreg, tw1, tw2, lb);
         }
         {
             unsigned t2 = tl;
@@ -1636,7 +1689,7 @@ __global__ __launch_bounds__(1024) void fft_c2c_rows_kernel(const C<float> *in, 
         if (fn < batch) load_frame(v, fn);
         unsigned la = lane;
         asm volatile("" : "+v"(la));
-        run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u, wreg, tw1, tw2, tw3, tw, la);
+        row_passes_1024(u, wreg, tw1, tw2, la);
         __syncthreads();  // the waves' regions alias the image
         C<T> *oimg = img + (size_t)OROW * wave + lane;
 #pragma unroll
@@ -1724,7 +1777,7 @@ __global__ __launch_bounds__(1024) void fft_c2c_rows32_kernel(const C<float> *in
         for (int s = 0; s < SPW; s++) {
             unsigned la = lane;
             asm volatile("" : "+v"(la));
-            run_passes<T, NS, 64, R0, R1, R2, 1, 2>(u[s], wreg, tw1, tw2, tw3, tw, la);
+            row_passes_1024(u[s], wreg, tw1, tw2, la);
         }
         __syncthreads();  // the waves' regions alias the image
         unsigned to = tl;
