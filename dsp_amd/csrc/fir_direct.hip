@@ -986,10 +986,14 @@ int launch_half(FirParams<float> p, const void *tab, float unscale, int ns, unsi
     p.ntiles_total = (unsigned)tiles;
     // A workgroup's first two tiles are loaded with nothing to overlap them, which asks for long
     // walks; an HBM-bound stream runs fastest as many short-lived workgroups.  Measured on 131072
-    // tiles: 16 tiles per workgroup up to 159 taps (0.80 ms; 0.82 with 32, 0.86 with 171 = one
-    // resident set walking everything), 32 beyond (305 taps: 1.06 ms against 1.07 with 16).
+    // tiles (one box): up to four slices (113 taps) 4 tiles per workgroup (33 taps 0.745 ms, 113
+    // taps 0.789; with 8 tiles 0.79, with 16 0.805 whatever the tap count), five and six slices 16
+    // (127 taps 0.806 ms; 0.864 with 4, 0.82 with 32, 0.86 with 171 = one resident set walking
+    // everything), 32 beyond (305 taps: 1.06 ms against 1.07 with 16).  Handing a workgroup tiles
+    // a grid apart instead of consecutive ones changes nothing at these settings (16 taps, 16
+    // tiles: 0.805 -> 0.762, level with 4 consecutive tiles' 0.748; 127 taps: 0.861 -> 0.866).
     unsigned tpb = (unsigned)(tiles / 8192);
-    const unsigned cap = ns > 6 ? 32 : 16;
+    const unsigned cap = ns > 6 ? 32 : ns > 4 ? 16 : 4;
     p.tiles_per_block = tpb < 2 ? (tiles >= 2048 ? 2 : 1) : (tpb > cap ? cap : tpb);
     {
         const char *env = getenv("DSPMI_FIR_TPB");  // experiment knob
@@ -1065,10 +1069,11 @@ int launch_split(FirParams<float> p, const void *tab, int ns, unsigned nchan, hi
 
 constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every NHB)
 // The f16 kernel takes every tap count its ten slices hold, from where the f32 matrix kernel stops
-// being as fast (measured, 512 x 2^20 samples: 33 taps 0.82 ms against 0.80; 63 taps 0.82 against
-// 0.93; 127 taps 0.82 against 1.03 for overlap-save and 0.98 for the bf16 kernel; 305 taps 1.09
-// against 1.16 for overlap-save).
-constexpr unsigned kSplitAutoMinTaps = 40;
+// being as fast (measured, 512 x 2^20 samples on one box: 17 and 24 taps 0.747 ms against 0.737 and
+// 0.745 for the f32 kernel; 33 taps 0.745 against 0.805; 63 taps 0.758 against 0.93; 127 taps 0.806
+// against 1.03 for overlap-save and 0.98 for the bf16 kernel; 305 taps 1.09 against 1.16 for
+// overlap-save).
+constexpr unsigned kSplitAutoMinTaps = 33;
 constexpr unsigned kOlsMinTaps = 64;  // measured crossover (direct 1.12 ms vs 1.08 at 64 taps; direct wins below)
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
@@ -1180,7 +1185,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     if (hist && hist_stride + 1 < pl->nh) return dspmi::fail(DSPMI_EINVAL, "fir_exec: hist_stride < nh-1");
     if (dspmi::rows_overlap(x, x_stride, nx, y, y_stride, nxx, nchan, sizeof(T)))
         return dspmi::fail(DSPMI_EINVAL, "fir_exec: input and output rows overlap (filtering in place is not supported)");
-    FirParams<T> p;
+    FirParams<T> p{};
     p.y = y; p.x = x; p.hist = hist; p.taps = static_cast<const T *>(pl->taps_dev);
     p.y_stride = y_stride; p.x_stride = x_stride; p.hist_stride = hist_stride;
     p.nxx = nxx; p.nx = nx; p.nh = pl->nh; p.nhp = pl->nhp; p.flags = flags;
@@ -1225,7 +1230,7 @@ int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *
 {
     if (!plan) return fail(DSPMI_EINVAL, "null FIR plan");
     if (!plan->half_tab)
-        return fail(DSPMI_ENOSYS, "the FIR plan runs %s, not the f16 matrix kernel (40..305 taps, or DSPMI_FIR_VARIANT=f16)", plan->name);
+        return fail(DSPMI_ENOSYS, "the FIR plan runs %s, not the f16 matrix kernel (33..305 taps, or DSPMI_FIR_VARIANT=f16)", plan->name);
     *images = plan->half_tab;
     *unscale = plan->half_unscale;
     *slices = plan->split_ns;
@@ -1296,7 +1301,7 @@ int dspmi_fir_exec_s16x2(dspmi_fir_t plan, int16_t *out, size_t out_stride, cons
         const size_t span_out = ((size_t)(nblock - 1) * out_stride + nsampl) * 4;
         if (a < b + span_out && b < a + span_in) return dspmi::fail(DSPMI_EINVAL, "fir_exec_s16x2: in and out overlap");
     }
-    FirParams<double> p;
+    FirParams<double> p{};
     p.y = reinterpret_cast<double *>(out); p.x = reinterpret_cast<const double *>(in); p.hist = nullptr;
     p.taps = static_cast<const double *>(plan->taps_dev);
     p.y_stride = out_stride; p.x_stride = in_stride; p.hist_stride = 0;

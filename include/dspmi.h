@@ -72,8 +72,8 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
 /* taps: nh HOST values, h[0] first.  device < 0 means the current device.
  * An f32 plan picks its kernel by tap count, every choice within the same 1e-6 (relative L2 per
  * 4096 outputs) of the double sum:
- *   up to 39 taps   f32 multiply-accumulate chains on the matrix unit;
- *   40 .. 305       the same sum through the f16 matrix pipe: samples and taps as two f16 parts
+ *   up to 32 taps   f32 multiply-accumulate chains on the matrix unit;
+ *   33 .. 305       the same sum through the f16 matrix pipe: samples and taps as two f16 parts
  *                   each, under one power-of-two scale per 4096-output tile, accumulated in f32.
  *                   A sample more than 2^39 below the largest of its tile is not carried, and a
  *                   non-finite sample makes its whole tile non-finite;
@@ -266,7 +266,7 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
  * ps[c * (nx / 4096) + f][k], k < nbin, is the normalised magnitude spectrum (mode, scale as
  * above; nbin = 2048 or 2049) of filtered samples 4096 f .. 4096 f + 4095 of channel c, the
  * filtered samples being those of dspmi_fir_exec_f32(fir, ..., nxx = nx, hist) -- they are never
- * written to memory.  fir: an f32 plan that runs the f16 matrix kernel (40 .. 305 taps); fft:
+ * written to memory.  fir: an f32 plan that runs the f16 matrix kernel (33 .. 305 taps); fft:
  * an f32 plan of 4096 points; nx a multiple of 4096.  DSPMI_ENOSYS for any other pair of plans:
  * the caller then makes the two calls. */
 int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode,

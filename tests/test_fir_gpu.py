@@ -102,8 +102,12 @@ def test_f32_parity(nh, nx, nchan, fir_path):
     for nxx in (nx, nx + nh):
         got, variant = run_f32(x, h, nxx)
         want = oracle.fir_batch_f32(x, h, nxx)
+        # the absolute term is the floor of the 16-bit kernels' parts (see assert_blocks): the one
+        # output of the 1-sample row under the 33-tap window is x[0] times an edge tap of 3e-19
+        floor = 2.0 ** -37 * np.sqrt(nh) * np.abs(h).max() * np.abs(x).max() if "mfma16x16x32" in variant else 0.0
         for c in range(nchan):
-            assert rel_l2(got[c], want[c]) <= TOL_FIR, (variant, nh, nx, nxx, c)
+            err = np.linalg.norm(got[c].astype(np.float64) - want[c])
+            assert err <= TOL_FIR * np.linalg.norm(want[c]) + floor * np.sqrt(nxx), (variant, nh, nx, nxx, c, err)
         if nxx == nx + nh:
             assert np.all(got[:, -1] == 0)  # the extra element of fft/src/main.c:190
 

@@ -21,7 +21,7 @@ ncase = 0
 worst = {}
 while time.time() - t0 < budget:
     variant = rng.choice(["f16", "bf16", "mfma", "ols", "auto"])
-    nh = int(rng.choice([rng.integers(1, 40), rng.integers(40, 306), rng.integers(306, 1200)], p=[0.2, 0.6, 0.2]))
+    nh = int(rng.choice([rng.integers(1, 33), rng.integers(33, 306), rng.integers(306, 1200)], p=[0.2, 0.6, 0.2]))
     if variant in ("f16", "bf16") and nh > 305:
         nh = int(rng.integers(1, 306))
     nx = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 70000)]))

@@ -1,5 +1,5 @@
 """Randomised check of dspmi_fir_spectrum_f32 against the two calls it replaces (FIR, then real
-transform + normalised magnitude): tap counts 40..305, channel and frame counts, history, modes,
+transform + normalised magnitude): tap counts 33..305, channel and frame counts, history, modes,
 input scales.  usage: python tools/spectrum_fuzz.py [seconds] [seed]"""
 import os
 import sys
@@ -17,7 +17,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fft = dsp_amd.FftPlan(4096, "f32")
 t0, ncase, worst = time.time(), 0, 0.0
 while time.time() - t0 < budget:
-    nh = int(rng.integers(40, 306))
+    nh = int(rng.integers(33, 306))
     h = (oracle.windowed_sinc_taps(nh) if rng.integers(0, 2) else rng.uniform(-1, 1, nh)).astype(np.float32)
     fir = dsp_amd.FirPlan(h, "f32")
     nchan, frames = int(rng.choice([1, 2, 5, rng.integers(6, 300)])), int(rng.choice([1, 2, 3, rng.integers(4, 20)]))
