@@ -334,7 +334,7 @@ def roofline(info, ms_per_launch):
                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(info),
                "launch_ms": round(ms_per_launch, 4),
                "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
-        if "mfma16x16x32" in info["kernel"] and info.get("nh", 0) * 2.0 / 8.0 > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
+        if info["kernel"].startswith("fir_f32_") and "mfma16x16x32" in info["kernel"] and info.get("nh", 0) * 2.0 / 8.0 > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
             # a direct-form kernel past the ridge of the f32 vector roof: that fraction too (it can exceed 1, the
             # products run on the 16-bit matrix pipe)
             out["fp32_vector_frac"] = round(info["flop_per_unit"] * info["units"] / sec / 1e12 / FP32_PEAK_TFLOPS, 4)
