@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
         // (they drift back into step after about ten).  With few rounds, the workgroups that stride
         // over one pair more than the others start at once and the others share the later
         // starts, which costs nothing at the end (their last round is the one they do not have);
-        // from four rounds on every workgroup takes part (the shorter period repays the late start:
+        // from eight rounds on every workgroup takes part (the shorter period repays the late start:
         // 2736 pairs 0.562 -> 0.534 ms, 2560 pairs 0.515 -> 0.489 ms).
         const unsigned extra = (unsigned)(total % gridDim.x);
         unsigned long long wait;
@@ -1442,7 +1442,8 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
         const char *env = getenv("DSPMI_OLS_STAGGER");
         a.stagger = env ? (unsigned)atoi(env) : 60000u;
         if (rounds < 2 || (total % grid == 0 && rounds < 4)) a.stagger = 0;
-        a.stagger_all = rounds >= 4;
+        a.stagger_all = rounds >= 8;  // 5.33 rounds: 0.265-0.273 ms with only the shorter walks delayed, 0.270-0.280 with all
+        if (const char *all = getenv("DSPMI_OLS_STAGGER_ALL")) a.stagger_all = (unsigned)atoi(all);  // experiment knob
     }
     // tables: exp(-2 pi i k / 1024), k < 1024, then the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]
     const C<float> *tw_sub = static_cast<const C<float> *>(tables);
