@@ -1054,6 +1054,7 @@ struct OlsArgs {
     unsigned nx, nh, L, nblk, npair, nchan;
     unsigned stagger = 0;  // ols_wave_kernel: spread of the workgroups' start times, in clock ticks
     unsigned stagger_all = 0;  // ... applied to every workgroup (many rounds), not only to those with a round less
+    unsigned prefetch = 0;     // ols_wave_kernel: the next block pair's input is requested ahead of this pair's stores
 };
 
 // The radix list is symmetric (R0 == last radix), so the positions a lane holds after the
@@ -1276,14 +1277,48 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
         // bounded by the clock, and by a count of sleeps in case the counter ticks at another rate
         for (unsigned naps = 0; naps < 64 && __builtin_readcyclecounter() - t0 < wait; naps++) __builtin_amdgcn_s_sleep(32);
     }
+    // Where a block pair lies: channel, pair within the channel, sample index of element 0 of the
+    // even block, whether the odd block exists, and whether every sample of both blocks does
+    // (the same answers for the whole workgroup).
+    struct Place {
+        size_t c;
+        unsigned p;
+        long base;
+        bool second, interior;
+    };
+    auto locate = [&](size_t frame) {
+        Place f;
+        f.c = frame / a.npair;
+        f.p = (unsigned)(frame - f.c * a.npair);
+        f.base = (long)(2 * f.p) * L - (nh - 1);
+        f.second = 2 * f.p + 1 < a.nblk;
+        f.interior = f.base >= 0 && f.base + L + K1 * NS <= nx && f.second;
+        return f;
+    };
+    // A pair's input requested while the pair before it is still being finished (a.prefetch,
+    // interior pairs only): the even block goes straight into the exchange image, which is idle
+    // from the last exchange of one pair to the first of the next (buffer loads with the LDS
+    // bit: no registers), the odd block into `ahead` once the last radix-K1 sum has freed the
+    // registers of the row phase -- both ahead of the pair's stores.  The wait for a pair's input
+    // is then a wait for operations older than those stores (the counter is in order); issued the
+    // other way round, every load waits behind 192 KB of stores per CU.  The stores themselves
+    // need not have completed until the stage factors, loaded at the top of the pair, are used
+    // after its first radix-K1 sum.  Measured on 2^26 samples, 8191 taps, alternating on one box:
+    // 0.279 -> 0.265 ms, 0.272 -> 0.266, 0.2685 -> 0.264.  (What-if builds: with the stores left out
+    // the launch takes 0.221 ms, with loads that hit the cache 0.242.  Requesting the stage
+    // factors ahead of the stores as well, or keeping them in registers across the pair boundary,
+    // costs more in registers than it hides: 0.272 - 0.283 ms.)
+    bool ready = false;
+    float ahead[K1];
     for (size_t frame = blockIdx.x; frame < total; frame += gridDim.x) {
-        const size_t c = frame / a.npair;
-        const unsigned p = (unsigned)(frame - c * a.npair);
+        const Place here = locate(frame);
+        const size_t c = here.c;
+        const unsigned p = here.p;
         const float *xrow = a.x + c * a.x_stride;
         const float *hrow = a.hist ? a.hist + c * a.hist_stride : nullptr;
-        const long base = (long)(2 * p) * L - (nh - 1);  // sample index of element 0 of the even block
-        const bool second = 2 * p + 1 < a.nblk;
-        const bool interior = base >= 0 && base + L + K1 * NS <= nx && second;  // the same for the whole workgroup
+        const long base = here.base;
+        const bool second = here.second;
+        const bool interior = here.interior;
         // laundered lane index: the stage factors and H are the same for every frame; hoisted out
         // of the frame loop they would occupy registers through both transforms
         unsigned tt = tl;
@@ -1291,7 +1326,37 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
 
         // element tl + 1024 n1 of the pair: re = x[base + ...], im = x[base + L + ...]
         C<T> v[K1];
-        if (interior) {
+        if (ready) {
+            // Everything but the youngest 48 memory operations -- the stores that followed the
+            // requests -- has completed: vmcnt(48).  Stated here, and the image read back in asm:
+            // before an LDS read the compiler can see it waits for every memory operation once
+            // a load into LDS is outstanding, stores included.  Each wave reads back the columns
+            // its own lanes requested (lane address + 4096 n1, two bases: the offset field ends at 65535).
+            __builtin_amdgcn_s_waitcnt(0xcf70);
+            const unsigned a0 = tl * 4u, a1 = tl * 4u + 65536u;
+#define DSPMI_READ16(base, v0)                                                                                         \
+    asm volatile("ds_read_b32 %0, %16\n ds_read_b32 %1, %16 offset:4096\n ds_read_b32 %2, %16 offset:8192\n"           \
+                 "ds_read_b32 %3, %16 offset:12288\n ds_read_b32 %4, %16 offset:16384\n ds_read_b32 %5, %16 offset:20480\n" \
+                 "ds_read_b32 %6, %16 offset:24576\n ds_read_b32 %7, %16 offset:28672\n ds_read_b32 %8, %16 offset:32768\n" \
+                 "ds_read_b32 %9, %16 offset:36864\n ds_read_b32 %10, %16 offset:40960\n ds_read_b32 %11, %16 offset:45056\n" \
+                 "ds_read_b32 %12, %16 offset:49152\n ds_read_b32 %13, %16 offset:53248\n ds_read_b32 %14, %16 offset:57344\n" \
+                 "ds_read_b32 %15, %16 offset:61440\n s_waitcnt lgkmcnt(0)"                                             \
+                 : "=&v"(v[v0].re), "=&v"(v[v0 + 1].re), "=&v"(v[v0 + 2].re), "=&v"(v[v0 + 3].re), "=&v"(v[v0 + 4].re),   \
+                   "=&v"(v[v0 + 5].re), "=&v"(v[v0 + 6].re), "=&v"(v[v0 + 7].re), "=&v"(v[v0 + 8].re), "=&v"(v[v0 + 9].re), \
+                   "=&v"(v[v0 + 10].re), "=&v"(v[v0 + 11].re), "=&v"(v[v0 + 12].re), "=&v"(v[v0 + 13].re),                \
+                   "=&v"(v[v0 + 14].re), "=&v"(v[v0 + 15].re)                                                           \
+                 : "v"(base)                                                                                           \
+                 : "memory")
+            static_assert(K1 == 32 && NS == 1024, "two groups of sixteen rows, 4096 bytes apart");
+            DSPMI_READ16(a0, 0);
+            DSPMI_READ16(a1, 16);
+#undef DSPMI_READ16
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                v[n1].im = ahead[n1];
+                asm volatile("" : "+v"(v[n1].im));  // the wait for it belongs here, not where the three paths meet
+            }
+        } else if (interior) {
             const float *p0 = xrow + base + tt;
             const float *p1 = p0 + L;
 #pragma unroll
@@ -1299,6 +1364,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
                 v[n1].re = __builtin_nontemporal_load(p0 + NS * n1);
                 v[n1].im = __builtin_nontemporal_load(p1 + NS * n1);
             }
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) asm volatile("" : "+v"(v[n1].re), "+v"(v[n1].im));  // (the wait for these, likewise)
         } else {
             auto sample = [&](long s) -> float {
                 if (s >= 0) return s < nx ? xrow[s] : 0.f;
@@ -1310,6 +1377,8 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
                 v[n1].re = sample(s);
                 v[n1].im = second ? sample(s + L) : 0.f;
             }
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) asm volatile("" : "+v"(v[n1].re), "+v"(v[n1].im));
         }
 
         // ---- first transform: radix-K1 sum, stage factors, rows ----
@@ -1376,25 +1445,86 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
             }
             __syncthreads();
         }
-        sf.apply(v);
+        sf.apply(v);  // (ahead of the requests below: its wait for the stage factors would be a wait for them too)
+        // The image is idle from here on: the next pair's even block lands in it.
+        const size_t after = frame + gridDim.x;
+        Place next{};
+        if (a.prefetch && interior && after < total) next = locate(after);
+        const bool fetch = next.interior;  // false unless located
+        const float *nrow = a.x + next.c * a.x_stride + next.base;
+        if (fetch) {
+            // Buffer loads with the LDS bit (a uniform descriptor over the pair's input, the lane's
+            // offset in one register, the row's in a scalar); the global_load_lds form would do as
+            // well, but the compiler then treats every later wait as "wait for everything".  The
+            // lane offset is tied to the last of the stage-factor products, so that the wait for
+            // the factors comes before these requests, not after them.
+            unsigned td = tl * 4u;
+            asm volatile("" : "+v"(td) : "v"(v[K1 - 1].re), "v"(v[K1 - 1].im));
+            const int nbytes = (int)((L + K1 * NS) * 4);
+            const unsigned col = 64u * (unsigned)__builtin_amdgcn_readfirstlane((int)wave);
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(uniform_descriptor(nrow, nbytes),
+                                                     (__attribute__((address_space(3))) void *)(img + NS * n1 + col), 4, (int)td,
+                                                     NS * n1 * 4, 0, 0);
+        }
         dft_reg<K1, 1>(v);
 
         // outputs j = m - (nh-1) >= 0 of each block of the pair; the result comes out swapped:
         // im belongs to the even block, re to the odd one
         unsigned to = tl;
-        asm volatile("" : "+v"(to));  // keeps the store predicates from being formed (and kept) early
+        asm volatile("" : "+v"(to) : "v"(v[0].re));  // keeps what follows from being formed (and kept) early
         if (interior) {
-            float *q0 = a.y + c * a.y_stride + ((long)(2 * p) * L - (nh - 1)) + to;
-            float *q1 = q0 + L;
+            // Stores through a descriptor over the pair's outputs (built at each use: a descriptor
+            // held in a variable that a lambda captures is kept in scratch memory): a lane whose
+            // element is overlap gets an offset that is out of range for any size.  The rows that
+            // can be overlap for every lane and are then skipped (up to 8192 taps: the first
+            // eight) go first; the others are all issued, after the loads of `ahead`: a store under
+            // a condition there would make the wait for `ahead` a wait for everything.
+            const float *ybase = a.y + c * a.y_stride + ((long)(2 * p) * L - (nh - 1));
+            const int ybytes = (int)((L + K1 * NS) * 4);
+#define DSPMI_YRSRC uniform_descriptor(ybase, ybytes)
             const int skip = (int)nh - 1 - (int)to;  // element offsets below this are overlap
+            auto store_row = [&](int n1) __attribute__((always_inline)) {
+                const int off = NS * n1 >= skip ? (int)(to + NS * n1) * 4 : 0x7ffffff0;
+                const int off1 = NS * n1 >= skip ? off + (int)L * 4 : 0x7ffffff0;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n1].im), DSPMI_YRSRC, off, 0, 2);  // nontemporal
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n1].re), DSPMI_YRSRC, off1, 0, 2);
+                __builtin_amdgcn_sched_barrier(0);  // offsets formed row by row, not all at once
+            };
 #pragma unroll
-            for (int n1 = 0; n1 < K1; n1++) {
-                if (NS * n1 >= skip) {
-                    __builtin_nontemporal_store(v[n1].im, q0 + NS * n1);
-                    __builtin_nontemporal_store(v[n1].re, q1 + NS * n1);
-                }
+            for (int n1 = 0; n1 < 8; n1++)
+                if (NS * n1 + NS > (int)nh - 1) store_row(n1);
+            if (fetch) {
+                const char *g = reinterpret_cast<const char *>(nrow + L);
+                const unsigned lo = to * 4u;
+#pragma unroll
+                for (int n1 = 0; n1 < K1; n1++)
+                    ahead[n1] = __builtin_nontemporal_load(reinterpret_cast<const float *>(g + (size_t)NS * n1 * 4 + (size_t)lo));
+            } else {
+                // (a value on every path: left alone, last round's values would stay live -- 32
+                // registers -- through the whole of the next pair)
+#pragma unroll
+                for (int n1 = 0; n1 < K1; n1++) ahead[n1] = 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n1 = 8; n1 < 16; n1++) store_row(n1);
+            // from row 16 on nothing is overlap (the transform is at least twice the tap count):
+            // one lane offset per block, the row's offset in a scalar
+            static_assert(K1 == 32, "rows 16 .. K1-1 are past any overlap");
+            const int lane_off = (int)to * 4, lane_off1 = lane_off + (int)L * 4;
+#pragma unroll
+            for (int n1 = 16; n1 < K1; n1++) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n1].im), DSPMI_YRSRC, lane_off, NS * n1 * 4, 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[n1].re), DSPMI_YRSRC, lane_off1, NS * n1 * 4, 2);
+            }
+#undef DSPMI_YRSRC
+            ready = fetch;
         } else {
+            ready = false;
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) ahead[n1] = 0.f;
             float *yrow = a.y + c * a.y_stride;
 #pragma unroll
             for (int n1 = 0; n1 < K1; n1++) {
@@ -1403,6 +1533,10 @@ __global__ __launch_bounds__(1024) void ols_wave_kernel(const OlsArgs a, const C
                 if (j >= 0 && o0 < nx) yrow[o0] = v[n1].im;
                 if (j >= 0 && second && o0 + L < nx) yrow[o0 + L] = v[n1].re;
             }
+            // vmcnt(0): nothing is outstanding where this path joins the other, so the compiler's
+            // count of what may still be in flight at the top of the loop is the other path's
+            // (these stores are conditional, and "perhaps none" would turn into "wait for all")
+            __builtin_amdgcn_s_waitcnt(0x0f70);
         }
     }
 }
@@ -1432,7 +1566,9 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
     if (total == 0) return DSPMI_OK;
     // one workgroup fits a CU: a resident set that strides over the block pairs (0.286 ms against
     // 0.294 with one workgroup per pair on 2^26 samples -- the twiddle tables are set up once)
-    const size_t grid = total < (size_t)num_cu ? total : (size_t)num_cu;
+    size_t grid = total < (size_t)num_cu ? total : (size_t)num_cu;
+    if (const char *g = getenv("DSPMI_OLS_GRID"))  // tests: few workgroups, so that short signals make each walk several pairs
+        if (atoi(g) > 0 && (size_t)atoi(g) < grid) grid = (size_t)atoi(g);
     {
         // start-time spread: 60000 ticks (~25 us, about 0.6 of a block pair's time) measured best
         // on 2^26 samples (0.289 -> 0.258 ms); with every workgroup striding over the same number
@@ -1444,6 +1580,8 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
         if (rounds < 2 || (total % grid == 0 && rounds < 4)) a.stagger = 0;
         a.stagger_all = rounds >= 8;  // 5.33 rounds: 0.265-0.273 ms with only the shorter walks delayed, 0.270-0.280 with all
         if (const char *all = getenv("DSPMI_OLS_STAGGER_ALL")) a.stagger_all = (unsigned)atoi(all);  // experiment knob
+        const char *pf = getenv("DSPMI_OLS_PREFETCH");  // 0 turns the early requests off (A/B)
+        a.prefetch = pf ? (unsigned)atoi(pf) : 1u;
     }
     // tables: exp(-2 pi i k / 1024), k < 1024, then the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]
     const C<float> *tw_sub = static_cast<const C<float> *>(tables);

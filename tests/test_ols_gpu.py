@@ -142,3 +142,33 @@ def test_fused_kernels_agree_with_the_five_kernel_composition(nh, fft_n, monkeyp
     for c in range(2):
         check_blocks(a[c], want[c], x[c], h, ("fused", nh, fft_n, c))
         check_blocks(b[c], want[c], x[c], h, ("composed", nh, fft_n, c))
+
+
+@pytest.mark.parametrize("nh", [2049, 8191, 16384])
+@pytest.mark.parametrize("grid", [1, 4, 7])
+def test_long_blocks_with_the_next_pair_requested_early(nh, grid, monkeypatch):
+    """32768-point blocks, few workgroups (DSPMI_OLS_GRID) so that each walks several block pairs:
+    from its second interior pair on a workgroup takes its input from the requests it issued
+    ahead of the previous pair's stores (even block through LDS, odd block through registers).
+    Checked against the oracle per block, and bit for bit against the same launch with the early
+    requests switched off (DSPMI_OLS_PREFETCH=0) -- the arithmetic is the same."""
+    rng = np.random.default_rng(nh + grid)
+    L = 32768 - (nh - 1)
+    nchan = 2
+    nx = 9 * L + 12345                      # ten blocks per row: five pairs, the last one ragged
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    xd, hd = torch.from_numpy(x).cuda(), torch.from_numpy(hist).cuda()
+    plan = dsp_amd.OlsPlan(h, 32768)
+    monkeypatch.setenv("DSPMI_OLS_GRID", str(grid))
+    early = plan.exec(xd, hist=hd).cpu().numpy()
+    monkeypatch.setenv("DSPMI_OLS_PREFETCH", "0")
+    plain = plan.exec(xd, hist=hd).cpu().numpy()
+    assert np.array_equal(early, plain)
+    if nh <= 8191:
+        full = np.concatenate([hist, x], axis=1)
+        want = oracle.fir_batch_f32(full, h, nh - 1 + nx)[:, nh - 1:]
+        for c in range(nchan):
+            check_blocks(early[c], want[c], x[c], h, (nh, grid, c))
+
