@@ -1,0 +1,62 @@
+"""Randomised check of the 32768-point overlap-save kernel: tap counts 2049..16384, row lengths, channel
+counts, history, few or many workgroups (DSPMI_OLS_GRID), start-time spread on and off.  Each case is run
+with the next pair's input requested early and without (DSPMI_OLS_PREFETCH=0): the outputs must be equal
+bit for bit; every fourth case is also held to the five-kernel composition (DSPMI_OLS_COMPOSED=1) within
+the FIR bound.  usage: python tools/ols_fuzz.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import dsp_amd
+import oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+ncase = 0
+worst = 0.0
+while time.time() - t0 < budget:
+    nh = int(rng.choice([2049, 4096, 8191, 16384, rng.integers(2049, 16385)]))
+    L = 32768 - (nh - 1)
+    npairs = int(rng.integers(1, 14))
+    nx = int(max(1, 2 * npairs * L - rng.integers(0, 2 * L)))
+    nchan = int(rng.choice([1, 2, 3, 5]))
+    grid = int(rng.choice([1, 2, 3, 5, 8, 1000]))
+    use_hist = bool(rng.integers(0, 2))
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = torch.from_numpy(rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)).cuda()
+    hist = torch.from_numpy(rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)).cuda() if use_hist else None
+    plan = dsp_amd.OlsPlan(h, 32768)
+    os.environ["DSPMI_OLS_GRID"] = str(grid)
+    os.environ["DSPMI_OLS_STAGGER"] = str(int(rng.choice([0, 60000])))
+    os.environ.pop("DSPMI_OLS_PREFETCH", None)
+    early = plan.exec(x, hist=hist).cpu().numpy()
+    os.environ["DSPMI_OLS_PREFETCH"] = "0"
+    plain = plan.exec(x, hist=hist).cpu().numpy()
+    os.environ.pop("DSPMI_OLS_PREFETCH")
+    if not np.array_equal(early, plain):
+        bad = np.argwhere(early != plain)
+        print("FAIL: early requests change the output", dict(nh=nh, nx=nx, nchan=nchan, grid=grid, hist=use_hist, first=bad[0].tolist(), count=len(bad)), flush=True)
+        sys.exit(1)
+    if ncase % 4 == 0:
+        os.environ["DSPMI_OLS_COMPOSED"] = "1"
+        ref = dsp_amd.OlsPlan(h, 32768)
+        del os.environ["DSPMI_OLS_COMPOSED"]
+        want = ref.exec(x, hist=hist).cpu().numpy().astype(np.float64)
+        for c in range(nchan):
+            for a in range(0, nx, 4096):
+                w = want[c, a:a + 4096]
+                err = np.linalg.norm(early[c, a:a + 4096] - w)
+                lim = 1e-6 * max(np.linalg.norm(w), np.linalg.norm(h) * np.sqrt(len(w) / 3.0))
+                if err > lim:
+                    print("FAIL: differs from the five-kernel composition", dict(nh=nh, nx=nx, nchan=nchan, grid=grid, chan=c, block=a, err=err, lim=lim), flush=True)
+                    sys.exit(1)
+                worst = max(worst, err / lim)
+    ncase += 1
+    if ncase % 25 == 0:
+        print("%d cases, %.0f s" % (ncase, time.time() - t0), flush=True)
+print("ok: %d cases in %.0f s; worst block difference from the composition %.2f of the bound" % (ncase, time.time() - t0, worst))
