@@ -376,6 +376,41 @@ __device__ __forceinline__ void row_passes_1024(C<float> *v, C<float> *lds, cons
     dft_reg<16, 1>(v);
 }
 
+// run_passes<float, 512, 64, 8, 8, 8, 1, 2> -- a 512-point frame inside one wave, eight points
+// per lane -- written the same way: pad(8 tl + r) = 8 tl + tl / 2 + r, pad(tl + 64 r) = pad(tl) + 68 r,
+// pad(64 (tl / 8) + tl % 8 + 8 r) = 68 (tl / 8) + tl % 8 + 8 r + r / 2.
+__device__ __forceinline__ void row_passes_512(C<float> *v, C<float> *lds, const C<float> *tw1, const C<float> *tw2, unsigned tl)
+{
+    const unsigned rb = tl + (tl >> 4);
+    const unsigned w1 = 8 * tl + (tl >> 1);
+    const unsigned w2 = 68 * (tl >> 3) + (tl & 7);
+    dft_reg<8, 1>(v);
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds[w1 + r] = v[r];
+    frame_sync<64>();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = lds[rb + 68 * r];
+    frame_sync<64>();
+    {
+        const C<float> *t = tw1 + (tl & 7);
+#pragma unroll
+        for (int r = 1; r < 8; r++) v[r] = cmul(v[r], t[8 * (r - 1)]);
+    }
+    dft_reg<8, 1>(v);
+#pragma unroll
+    for (int r = 0; r < 8; r++) lds[w2 + 8 * r + (r >> 1)] = v[r];
+    frame_sync<64>();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = lds[rb + 68 * r];
+    frame_sync<64>();
+    {
+        const C<float> *t = tw2 + tl;
+#pragma unroll
+        for (int r = 1; r < 8; r++) v[r] = cmul(v[r], t[64 * (r - 1)]);
+    }
+    dft_reg<8, 1>(v);
+}
+
 template <int NT> constexpr int block_threads() { return NT > 256 ? NT : 256; }
 
 // Workgroups to launch for `nfb` frame-blocks when `resident` fit the chip at once.  A grid of
@@ -1218,15 +1253,15 @@ __global__ __launch_bounds__((ols_block_threads<N, NT>())) __attribute__((amdgpu
 // the frame and sit in registers until the radix-K1 sum is done); the others are applied as
 // two factors, W^(4a n2) and W^(b n2): one more rounding on those points (the block error stays
 // at 2.1e-7).
-template <int K1>
+template <int K1, int NS = 1024>
 struct StageFactors {
     C<float> lo[3], hi[K1 / 4 - 1];
     __device__ __forceinline__ void load(const C<float> *tp)
     {
 #pragma unroll
-        for (int b = 1; b < 4; b++) lo[b - 1] = tp[1024 * b];
+        for (int b = 1; b < 4; b++) lo[b - 1] = tp[NS * b];
 #pragma unroll
-        for (int a = 1; a < K1 / 4; a++) hi[a - 1] = tp[1024 * 4 * a];
+        for (int a = 1; a < K1 / 4; a++) hi[a - 1] = tp[NS * 4 * a];
     }
     __device__ __forceinline__ void apply(C<float> *v) const
     {
@@ -1586,6 +1621,324 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
     // tables: exp(-2 pi i k / 1024), k < 1024, then the stage factors exp(-2 pi i k1 n2 / N) as [k1][n2]
     const C<float> *tw_sub = static_cast<const C<float> *>(tables);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, a, tw_sub, tw_sub + NS);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// overlap-save, long blocks, one real block per transform: 32768 samples as 16384 complex
+// points, two workgroups of 512 lanes per CU
+// ---------------------------------------------------------------------------
+
+// ols_wave_kernel fits one workgroup on a CU, and everything between its row phases is done
+// by all sixteen waves in step: while they exchange through LDS, wait at a barrier or wait for
+// memory, nothing else is there to run.  Here a block of M = 2 N2 real samples rides one N2-point
+// complex transform as z[n] = x[2n] + i x[2n+1] (N2 = K1 * 512 = 16384), which halves the frame:
+// 32 points per lane of a 512-lane workgroup, a 64 KB exchange image, two workgroups per CU that
+// run out of step and fill each other's gaps.  The factorisation is ols_wave_kernel's
+// (n = n2 + 512 n1, k = k1 + K1 k2; radix-K1 sum and stage factors in registers, one exchange,
+// 512-point rows inside a wave).
+// What replaces the multiplication by H: with h split into its even and odd samples,
+// Hev = FFT_N2(h[0::2]), Hod = FFT_N2(h[1::2]), the packed spectrum of the filtered block is
+//   Zy[k] = Hev[k] Z[k] + (i/2) Hod[k] (S - w D),   S = Z[k] + conj Z[N2-k], D = Z[k] - conj Z[N2-k],
+//   w = exp(-2 pi i k / N2)
+// (S/2 and -iD/2 are the spectra of the even and odd input samples; the odd taps delay the odd
+// samples by one even sample: the factor w), and for the partner bin
+//   Zy[N2-k] = Hev[N2-k] Z[N2-k] + (i/2) Hod[N2-k] conj(S + w D).
+// Bin k = k1 + K1 k2 and its partner N2-k sit in rows k1 and (K1 - k1) mod K1, at positions k2 and
+// 511 - k2 (row 0: 512 - k2): a wave is given both rows of a pair -- (1,31), (2,30) .. (15,17), and
+// rows 0 and 16, which pair with themselves -- so the partner of what lane l holds in register r
+// is in lane 63-l, register 7-r of the other row, one cross-lane read away.  A lane of a pair of
+// rows works out both bins and hands the partner's result back the same way; the two rows that
+// pair with themselves work out every bin from its own side.
+// Tables (H): [0] Hev / N2, [1] (i/2) Hod / N2, both row by row ([k1][k2]).  (tw): exp(-2 pi i k / 512),
+// k < 512; the stage factors exp(-2 pi i k1 n2 / N2) as [k1][n2]; exp(-2 pi i (k1 + K1 l) / N2) as
+// [k1][l], l < 64 (the factor w of a lane's register 0; register r has w . exp(-2 pi i r / 8)).
+
+__device__ __forceinline__ C<float> lane_read(unsigned byte_addr, C<float> q)
+{
+    return {__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)byte_addr, __builtin_bit_cast(int, q.re))),
+            __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)byte_addr, __builtin_bit_cast(int, q.im)))};
+}
+
+// multiply-accumulate on complex numbers: acc + a b
+__device__ __forceinline__ C<float> cmla(C<float> acc, C<float> a, C<float> b)
+{
+    return {acc.re + a.re * b.re - a.im * b.im, acc.im + a.re * b.im + a.im * b.re};
+}
+
+// Rows a and b = K1 - a of one wave, spectra in, swapped filtered spectra out (the second
+// transform is swap . forward . swap).  he/g point at this lane's entry of row a; the partner
+// bin's factors need no tables: the taps are real, so Hev[N2-k] = conj Hev[k] and
+// (i/2) Hod[N2-k] = -conj((i/2) Hod[k]).
+template <int r>
+__device__ __forceinline__ void pair_step(C<float> *ua, C<float> *ub, const C<float> *he, const C<float> *g, C<float> w0,
+                                          unsigned rev)
+{
+    const C<float> A = ua[r], B = lane_read(rev, ub[7 - r]);
+    const C<float> hk = he[r], gk = g[r];
+    const C<float> S = {A.re + B.re, A.im - B.im}, D = {A.re - B.re, A.im + B.im};
+    const C<float> t = cmul(mul_w32<4 * r>(w0), D);
+    const C<float> U = {S.re - t.re, S.im - t.im}, V = {S.re + t.re, S.im + t.im};
+    const C<float> zk = cmla(cmul(hk, A), gk, U);
+    // conj(hk) B - conj(gk) conj(V) = conj(hk conj(B) - gk V)
+    const C<float> q = cmla(cmul(hk, C<float>{B.re, -B.im}), C<float>{-gk.re, -gk.im}, V);
+    ua[r] = {zk.im, zk.re};
+    ub[7 - r] = lane_read(rev, C<float>{-q.im, q.re});  // conj(q), swapped
+}
+template <int... R>
+__device__ __forceinline__ void pair_rows(C<float> *ua, C<float> *ub, const C<float> *he, const C<float> *g, C<float> w0,
+                                          unsigned rev, std::integer_sequence<int, R...>)
+{
+    (pair_step<R>(ua, ub, he, g, w0, rev), ...);
+}
+
+// A row that pairs with itself: the partner of register r is register 7-r of lane `from` / 4
+// (row 16: 63 - lane; row 0: (64 - lane) mod 64, and lane 0 pairs its own register r with
+// register (8 - r) mod 8).
+template <int r>
+__device__ __forceinline__ void self_step(C<float> *u, const C<float> *b, const C<float> *he, const C<float> *g, C<float> w0)
+{
+    const C<float> A = u[r], B = b[r];
+    const C<float> S = {A.re + B.re, A.im - B.im}, D = {A.re - B.re, A.im + B.im};
+    const C<float> t = cmul(mul_w32<4 * r>(w0), D);
+    const C<float> U = {S.re - t.re, S.im - t.im};
+    const C<float> zk = cmla(cmul(he[r], A), g[r], U);
+    u[r] = {zk.im, zk.re};
+}
+template <bool ROW0, int... R>
+__device__ __forceinline__ void pair_self(C<float> *u, const C<float> *he, const C<float> *g, C<float> w0, unsigned from,
+                                          bool lane0, std::integer_sequence<int, R...>)
+{
+    C<float> b[8];
+    ((b[R] = lane_read(from, u[7 - R])), ...);
+    if constexpr (ROW0) {
+        ((b[R] = lane0 ? u[(8 - R) & 7] : b[R]), ...);
+    }
+    (self_step<R>(u, b, he, g, w0), ...);
+}
+
+template <int K1>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void ols_real_kernel(const OlsArgs a,
+                                                                                                  const C<float> *__restrict__ tw_sub,
+                                                                                                  const C<float> *__restrict__ tw_stage,
+                                                                                                  const C<float> *__restrict__ tw_bin)
+{
+    typedef float T;
+    constexpr int NS = 512, NW = 8, N2 = K1 * NS, M = 2 * N2;
+    static_assert(K1 == 32, "sixteen pairs of rows over eight waves");
+    constexpr std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7> regs{};
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned tl = threadIdx.x, lane = tl & 63, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tl >> 6));
+    float *img = reinterpret_cast<float *>(smem_raw);  // [K1][512], one component at a time
+    C<T> *wreg = reinterpret_cast<C<T> *>(smem_raw) + (size_t)wave * padded_len(NS);
+    static_assert((size_t)NW * padded_len(NS) * sizeof(C<T>) <= (size_t)N2 * sizeof(float), "the waves' regions alias the image");
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    setup_lds_twiddles<T, NS, 512, 0, 8, 8, 8, 1>(smem_raw + (size_t)N2 * sizeof(float), tw_sub, tw1, tw2, tw3);
+
+    // the rows of this wave: s = 0, 1 one pair, s = 2, 3 the other
+    const unsigned row[4] = {2 * wave, wave ? K1 - 2 * wave : K1 / 2, 2 * wave + 1, K1 - 1 - 2 * wave};
+
+    const long nx = a.nx, nh = a.nh, L = a.L;
+    const size_t total = (size_t)a.nchan * a.nblk;
+    if (a.stagger) {
+        // Workgroups that start together stay in step across the chip: every CU loads and stores
+        // at the same moment -- a burst HBM needs microseconds to move while every CU waits -- and
+        // then every CU computes while HBM idles (with the memory phases left out the launch takes
+        // 0.17 ms instead of 0.26: what the bytes cost at HBM's streaming rate).  The start times
+        // are spread over about a block's time; the workgroups that walk one block more than the
+        // others start at once (see ols_wave_kernel).
+        const unsigned extra = (unsigned)(total % gridDim.x);
+        unsigned long long wait;
+        if (a.stagger_all) wait = (unsigned long long)a.stagger * blockIdx.x / gridDim.x;
+        else wait = blockIdx.x < extra ? 0 : (unsigned long long)a.stagger * (blockIdx.x - extra + (extra ? 1 : 0)) / (gridDim.x - extra);
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        for (unsigned naps = 0; naps < 128 && __builtin_readcyclecounter() - t0 < wait; naps++) __builtin_amdgcn_s_sleep(32);
+    }
+    // 8-byte accesses: the block starts on an even sample of a row that starts on an 8-byte boundary
+    const bool even = !((nh - 1) & 1) && !(a.x_stride & 1) && !(a.y_stride & 1) && !((reinterpret_cast<size_t>(a.x) | reinterpret_cast<size_t>(a.y)) & 7);
+    for (size_t frame = blockIdx.x; frame < total; frame += gridDim.x) {
+        const size_t c = frame / a.nblk;
+        const unsigned blk = (unsigned)(frame - c * a.nblk);
+        const float *xrow = a.x + c * a.x_stride;
+        const float *hrow = a.hist ? a.hist + c * a.hist_stride : nullptr;
+        const long base = (long)blk * L - (nh - 1);  // sample index of element 0 of the block
+        const bool interior = even && base >= 0 && base + M <= nx;
+        unsigned tt = tl;
+        asm volatile("" : "+v"(tt));  // (see ols_wave_kernel: keeps per-frame addresses from being formed once and kept)
+
+        // element n = tl + 512 n1 of the block: re = x[base + 2n], im = x[base + 2n + 1]
+        C<T> v[K1];
+        if (interior) {
+            const C<T> *p0 = reinterpret_cast<const C<T> *>(xrow + ((a.prefetch & 8) ? (long)M * (blockIdx.x & 7) : base)) + tt;
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) v[n1] = nt_load(p0 + NS * n1);
+        } else {
+            auto sample = [&](long s) -> float {
+                if (s >= 0) return s < nx ? xrow[s] : 0.f;
+                return (hrow && s >= 1 - nh) ? hrow[nh - 1 + s] : 0.f;
+            };
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                const long s = base + 2 * (long)(tt + NS * n1);
+                v[n1].re = sample(s);
+                v[n1].im = sample(s + 1);
+            }
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < K1; n1++) asm volatile("" : "+v"(v[n1].re), "+v"(v[n1].im));
+
+        // ---- first transform: radix-K1 sum, stage factors, rows ----
+        StageFactors<K1, NS> sf;
+        sf.load(tw_stage + tt);
+        if (!(a.prefetch & 4)) {
+        dft_reg<K1, 1>(v);
+        sf.apply(v);
+        }
+        C<T> u[4][8];
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+#pragma unroll
+            for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = comp ? v[k1].im : v[k1].re;
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float q = img[NS * row[s] + lane + 64 * r];
+                    if (comp) u[s][r].im = q;
+                    else u[s][r].re = q;
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            C<T> *ua = u[2 * pr], *ub = u[2 * pr + 1];
+            const unsigned ra = row[2 * pr], rb = row[2 * pr + 1];
+            unsigned la = lane, lb = lane, lh = lane;
+            asm volatile("" : "+v"(la));
+            if (!(a.prefetch & 1)) row_passes_512(ua, wreg, tw1, tw2, la);
+            asm volatile("" : "+v"(lb));
+            if (!(a.prefetch & 1)) row_passes_512(ub, wreg, tw1, tw2, lb);
+            // the factors of this pair of rows, all requested before the first is used (one wait
+            // for memory per pair of rows, not one per register)
+            asm volatile("" : "+v"(lh));
+            const C<T> *he = a.H + (size_t)NS * ra + lh, *heb = a.H + (size_t)NS * rb + lh;
+            const bool self = pr == 0 && wave == 0;
+            C<T> hk[8], gk[8];
+            const C<T> w0 = tw_bin[64 * ra + lh];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                hk[r] = he[64 * r];
+                gk[r] = he[N2 + 64 * r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) asm volatile("" : "+v"(hk[r].re), "+v"(hk[r].im), "+v"(gk[r].re), "+v"(gk[r].im));
+            if (a.prefetch & 2) {
+            } else if (self) {
+                pair_self<true>(ua, hk, gk, w0, ((64u - lh) & 63u) * 4u, lh == 0, regs);
+                const C<T> w0b = tw_bin[64 * rb + lh];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    hk[r] = heb[64 * r];
+                    gk[r] = heb[N2 + 64 * r];
+                }
+                pair_self<false>(ub, hk, gk, w0b, (63u - lh) * 4u, false, regs);
+            } else {
+                pair_rows(ua, ub, hk, gk, w0, (63u - lh) * 4u, regs);
+            }
+            // ---- second transform: rows, stage factors, radix-K1 sum ----
+            asm volatile("" : "+v"(la));
+            if (!(a.prefetch & 1)) row_passes_512(ua, wreg, tw1, tw2, la);
+            asm volatile("" : "+v"(lb));
+            if (!(a.prefetch & 1)) row_passes_512(ub, wreg, tw1, tw2, lb);
+        }
+        {
+            unsigned t2 = tl;
+            asm volatile("" : "+v"(t2));
+            sf.load(tw_stage + t2);  // on their way during the exchange
+        }
+        __syncthreads();  // the waves' regions alias the image: every wave is done with its rows
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) img[NS * row[s] + lane + 64 * r] = comp ? u[s][r].im : u[s][r].re;
+            __syncthreads();
+#pragma unroll
+            for (int k1 = 0; k1 < K1; k1++) {
+                const float q = img[NS * k1 + tl];
+                if (comp) v[k1].im = q;
+                else v[k1].re = q;
+            }
+            __syncthreads();
+        }
+        if (!(a.prefetch & 4)) {
+        sf.apply(v);
+        dft_reg<K1, 1>(v);
+        }
+
+        // sample m = 2n (+1) of the block is output m - (nh-1) of it; the result comes out
+        // swapped: im is the even sample, re the odd one
+        unsigned to = tl;
+        asm volatile("" : "+v"(to) : "v"(v[0].re));
+        float *yrow = a.y + c * a.y_stride;
+        if (interior) {
+            C<T> *q0 = reinterpret_cast<C<T> *>(yrow + ((a.prefetch & 16) ? (long)M * (blockIdx.x & 7) : base)) + to;
+            const int skip = (int)(nh - 1) / 2 - (int)to;  // element offsets below this are overlap
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++)
+                if (NS * n1 >= skip) nt_store(C<T>{v[n1].im, v[n1].re}, q0 + NS * n1);
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < K1; n1++) {
+                const long j = 2 * (long)(to + NS * n1) - (nh - 1);
+                const long o0 = (long)blk * L + j;
+                if (j >= 0 && o0 < nx) yrow[o0] = v[n1].im;
+                if (j + 1 >= 0 && o0 + 1 < nx) yrow[o0 + 1] = v[n1].re;
+            }
+        }
+    }
+}
+
+template <int K1>
+int launch_ols_real(const dspmi::OlsLaunch &o, const void *tables, int num_cu, hipStream_t s)
+{
+    constexpr int NS = 512, N2 = K1 * NS, M = 2 * N2;
+    constexpr size_t lds = (size_t)N2 * sizeof(float) + lds_twiddle_entries(2, 8, 8, 8, 1) * sizeof(C<float>);
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    auto kern = ols_real_kernel<K1>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    OlsArgs a;
+    a.x = o.x; a.hist = o.hist; a.y = o.y; a.H = static_cast<const C<float> *>(o.H);
+    a.x_stride = o.x_stride; a.y_stride = o.y_stride; a.hist_stride = o.hist_stride;
+    a.nx = o.nx; a.nh = o.nh; a.L = M - (o.nh - 1);
+    a.nblk = (unsigned)(((unsigned long long)o.nx + a.L - 1) / a.L);
+    a.npair = a.nblk;
+    a.nchan = o.nchan;
+    const size_t total = (size_t)a.nchan * a.nblk;
+    if (total == 0) return DSPMI_OK;
+    size_t grid = total < (size_t)2 * num_cu ? total : (size_t)2 * num_cu;
+    if (const char *g = getenv("DSPMI_OLS_GRID"))  // tests: few workgroups, so that short signals make each walk several blocks
+        if (atoi(g) > 0 && (size_t)atoi(g) < grid) grid = (size_t)atoi(g);
+    {
+        const char *env = getenv("DSPMI_OLS_STAGGER");
+        a.stagger = env ? (unsigned)atoi(env) : 0u;
+        if (grid < (size_t)2 * num_cu) a.stagger = 0;
+        if (const char *all = getenv("DSPMI_OLS_STAGGER_ALL")) a.stagger_all = (unsigned)atoi(all);
+        if (const char *w = getenv("DSPMI_OLS_WHATIF")) a.prefetch = (unsigned)atoi(w);
+    }
+    if (const char *g = getenv("DSPMI_OLS_GRIDX"))  // experiment: resident set times this
+        if (atoi(g) > 0) grid = total < (size_t)atoi(g) * num_cu ? total : (size_t)atoi(g) * num_cu;
+    // tables: exp(-2 pi i k / 512), k < 512; the stage factors [K1][512]; the bin factors [K1][64]
+    const C<float> *tw_sub = static_cast<const C<float> *>(tables);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, a, tw_sub, tw_sub + NS, tw_sub + NS + N2);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
@@ -2234,6 +2587,8 @@ bluestein_launch_fn bluestein_find(unsigned m, int precision)
         if (e.m == m) return e.fn;
     return nullptr;
 }
+
+ols_launch_fn ols_find_real(unsigned block) { return block == 32768 ? launch_ols_real<32> : nullptr; }
 
 ols_launch_fn ols_find(unsigned n)
 {

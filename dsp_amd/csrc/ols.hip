@@ -135,6 +135,7 @@ struct dspmi_ols_plan {
     unsigned nh = 0, N = 0, L = 0;
     const dspmi::FftKernel *kern = nullptr;
     dspmi::ols_launch_fn fused = nullptr;  // one-kernel form (nullptr: composed path below)
+    bool real_blocks = false;              // fused = the kernel that runs one real block per N/2-point transform
     void *tw = nullptr;    // exp(-2 pi i k / N)
     void *H = nullptr;     // FFT_N(taps) / N
     void *work = nullptr;  // [nchan][npair][N] complex
@@ -169,6 +170,15 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     pl->L = N - (nh - 1);
     pl->kern = dspmi::fft_find(N, DSPMI_F32);  // the composed path's transform; none beyond 16384 points
     if (!composed) pl->fused = dspmi::ols_find(N);
+    {
+        // 32768-sample blocks: one real block per 16384-point transform, two workgroups per CU
+        // (DSPMI_OLS_REAL=0 keeps the kernel that runs two blocks through a 32768-point transform)
+        const char *env = getenv("DSPMI_OLS_REAL");
+        if (!composed && !(env && !atoi(env)) && dspmi::ols_find_real(N)) {
+            pl->fused = dspmi::ols_find_real(N);
+            pl->real_blocks = true;
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) pl->num_cu = prop.multiProcessorCount;
 
@@ -179,7 +189,30 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     const unsigned rows = (N > 16384 && !composed) ? N / 1024 : 0;  // the five-kernel composition keeps the plain layout
     const long double two_pi = 6.283185307179586476925286766559005768L;
     std::vector<C32> tw(rows ? 1024 + (size_t)N : N), h(N, C32{0.f, 0.f});
-    if (rows) {
+    if (pl->real_blocks) {
+        // ols_real_kernel (fft_stockham.hip): N2 = N/2 complex points as 32 rows of 512
+        const unsigned N2 = N / 2, K1 = 32, NS = 512;
+        tw.assign((size_t)NS + N2 + K1 * 64, C32{0.f, 0.f});
+        auto unit = [&](unsigned long long e, unsigned n) {
+            const long double a = -two_pi * (long double)(e % n) / (long double)n;
+            return C32{(float)cosl(a), (float)sinl(a)};
+        };
+        for (unsigned k = 0; k < NS; k++) tw[k] = unit(k, NS);
+        for (unsigned k1 = 0; k1 < K1; k1++)
+            for (unsigned n2 = 0; n2 < NS; n2++) tw[NS + (size_t)k1 * NS + n2] = unit((unsigned long long)k1 * n2, N2);
+        for (unsigned k1 = 0; k1 < K1; k1++)
+            for (unsigned l = 0; l < 64; l++) tw[(size_t)NS + N2 + k1 * 64 + l] = unit(k1 + K1 * l, N2);
+        // [0] Hev / N2, [1] (i/2) Hod / N2: the transforms of the even and the odd taps, row by row
+        std::vector<std::complex<double>> he(N2, {0.0, 0.0}), ho(N2, {0.0, 0.0});
+        for (unsigned j = 0; j < nh; j++) (j & 1 ? ho : he)[j / 2] = {(double)taps[j], 0.0};
+        host_fft(he);
+        host_fft(ho);
+        for (unsigned k = 0; k < N2; k++) {
+            const size_t at = (size_t)(k % K1) * NS + k / K1;
+            h[at] = {(float)(he[k].real() / N2), (float)(he[k].imag() / N2)};
+            h[N2 + at] = {(float)(-0.5 * ho[k].imag() / N2), (float)(0.5 * ho[k].real() / N2)};
+        }
+    } else if (rows) {
         for (unsigned k = 0; k < 1024; k++) {
             const long double a = -two_pi * (long double)k / 1024.0L;
             tw[k] = {(float)cosl(a), (float)sinl(a)};
@@ -195,7 +228,7 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
             tw[k] = {(float)cosl(a), (float)sinl(a)};
         }
     }
-    {
+    if (!pl->real_blocks) {
         // H = FFT_N(taps) / N
         std::vector<std::complex<double>> hz(N, {0.0, 0.0});
         for (unsigned j = 0; j < nh; j++) hz[j] = {(double)taps[j], 0.0};
