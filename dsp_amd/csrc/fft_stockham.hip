@@ -1676,7 +1676,7 @@ __device__ __forceinline__ void pair_step(C<float> *ua, C<float> *ub, const C<fl
                                           unsigned rev)
 {
     const C<float> A = ua[r], B = lane_read(rev, ub[7 - r]);
-    const C<float> hk = he[r], gk = g[r];
+    const C<float> hk = he[64 * r], gk = g[64 * r];
     const C<float> S = {A.re + B.re, A.im - B.im}, D = {A.re - B.re, A.im + B.im};
     const C<float> t = cmul(mul_w32<4 * r>(w0), D);
     const C<float> U = {S.re - t.re, S.im - t.im}, V = {S.re + t.re, S.im + t.im};
@@ -1703,7 +1703,7 @@ __device__ __forceinline__ void self_step(C<float> *u, const C<float> *b, const 
     const C<float> S = {A.re + B.re, A.im - B.im}, D = {A.re - B.re, A.im + B.im};
     const C<float> t = cmul(mul_w32<4 * r>(w0), D);
     const C<float> U = {S.re - t.re, S.im - t.im};
-    const C<float> zk = cmla(cmul(he[r], A), g[r], U);
+    const C<float> zk = cmla(cmul(he[64 * r], A), g[64 * r], U);
     u[r] = {zk.im, zk.re};
 }
 template <bool ROW0, int... R>
@@ -1742,28 +1742,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     const long nx = a.nx, nh = a.nh, L = a.L;
     const size_t total = (size_t)a.nchan * a.nblk;
-    if (a.stagger) {
-        // Workgroups that start together stay in step across the chip: every CU loads and stores
-        // at the same moment -- a burst HBM needs microseconds to move while every CU waits -- and
-        // then every CU computes while HBM idles (with the memory phases left out the launch takes
-        // 0.17 ms instead of 0.26: what the bytes cost at HBM's streaming rate).  The start times
-        // are spread over about a block's time; the workgroups that walk one block more than the
-        // others start at once (see ols_wave_kernel).
-        const unsigned extra = (unsigned)(total % gridDim.x);
-        unsigned long long wait;
-        if (a.stagger_all) wait = (unsigned long long)a.stagger * blockIdx.x / gridDim.x;
-        else wait = blockIdx.x < extra ? 0 : (unsigned long long)a.stagger * (blockIdx.x - extra + (extra ? 1 : 0)) / (gridDim.x - extra);
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        for (unsigned naps = 0; naps < 128 && __builtin_readcyclecounter() - t0 < wait; naps++) __builtin_amdgcn_s_sleep(32);
-    }
-    // 8-byte accesses: the block starts on an even sample of a row that starts on an 8-byte boundary
-    const bool even = !((nh - 1) & 1) && !(a.x_stride & 1) && !(a.y_stride & 1) && !((reinterpret_cast<size_t>(a.x) | reinterpret_cast<size_t>(a.y)) & 7);
+    // Blocks overlap by an even number of samples (nh-1, or nh when that is odd), so that every
+    // block starts on an even sample: 8-byte accesses when the rows start on 8-byte boundaries
+    const long ov = M - L;
+    const bool even = !(a.x_stride & 1) && !(a.y_stride & 1) && !((reinterpret_cast<size_t>(a.x) | reinterpret_cast<size_t>(a.y)) & 7);
     for (size_t frame = blockIdx.x; frame < total; frame += gridDim.x) {
         const size_t c = frame / a.nblk;
         const unsigned blk = (unsigned)(frame - c * a.nblk);
         const float *xrow = a.x + c * a.x_stride;
         const float *hrow = a.hist ? a.hist + c * a.hist_stride : nullptr;
-        const long base = (long)blk * L - (nh - 1);  // sample index of element 0 of the block
+        const long base = (long)blk * L - ov;  // sample index of element 0 of the block
         const bool interior = even && base >= 0 && base + M <= nx;
         unsigned tt = tl;
         asm volatile("" : "+v"(tt));  // (see ols_wave_kernel: keeps per-frame addresses from being formed once and kept)
@@ -1771,7 +1759,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // element n = tl + 512 n1 of the block: re = x[base + 2n], im = x[base + 2n + 1]
         C<T> v[K1];
         if (interior) {
-            const C<T> *p0 = reinterpret_cast<const C<T> *>(xrow + ((a.prefetch & 8) ? (long)M * (blockIdx.x & 7) : base)) + tt;
+            const C<T> *p0 = reinterpret_cast<const C<T> *>(xrow + base) + tt;
 #pragma unroll
             for (int n1 = 0; n1 < K1; n1++) v[n1] = nt_load(p0 + NS * n1);
         } else {
@@ -1792,10 +1780,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // ---- first transform: radix-K1 sum, stage factors, rows ----
         StageFactors<K1, NS> sf;
         sf.load(tw_stage + tt);
-        if (!(a.prefetch & 4)) {
         dft_reg<K1, 1>(v);
         sf.apply(v);
-        }
         C<T> u[4][8];
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
@@ -1818,41 +1804,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const unsigned ra = row[2 * pr], rb = row[2 * pr + 1];
             unsigned la = lane, lb = lane, lh = lane;
             asm volatile("" : "+v"(la));
-            if (!(a.prefetch & 1)) row_passes_512(ua, wreg, tw1, tw2, la);
+            row_passes_512(ua, wreg, tw1, tw2, la);
             asm volatile("" : "+v"(lb));
-            if (!(a.prefetch & 1)) row_passes_512(ub, wreg, tw1, tw2, lb);
-            // the factors of this pair of rows, all requested before the first is used (one wait
-            // for memory per pair of rows, not one per register)
+            row_passes_512(ub, wreg, tw1, tw2, lb);
+            // the spectrum of the filtered block, from each bin and its partner
             asm volatile("" : "+v"(lh));
             const C<T> *he = a.H + (size_t)NS * ra + lh, *heb = a.H + (size_t)NS * rb + lh;
-            const bool self = pr == 0 && wave == 0;
-            C<T> hk[8], gk[8];
-            const C<T> w0 = tw_bin[64 * ra + lh];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                hk[r] = he[64 * r];
-                gk[r] = he[N2 + 64 * r];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) asm volatile("" : "+v"(hk[r].re), "+v"(hk[r].im), "+v"(gk[r].re), "+v"(gk[r].im));
-            if (a.prefetch & 2) {
-            } else if (self) {
-                pair_self<true>(ua, hk, gk, w0, ((64u - lh) & 63u) * 4u, lh == 0, regs);
-                const C<T> w0b = tw_bin[64 * rb + lh];
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    hk[r] = heb[64 * r];
-                    gk[r] = heb[N2 + 64 * r];
-                }
-                pair_self<false>(ub, hk, gk, w0b, (63u - lh) * 4u, false, regs);
+            if (pr == 0 && wave == 0) {
+                pair_self<true>(ua, he, he + N2, tw_bin[64 * ra + lh], ((64u - lh) & 63u) * 4u, lh == 0, regs);
+                pair_self<false>(ub, heb, heb + N2, tw_bin[64 * rb + lh], (63u - lh) * 4u, false, regs);
             } else {
-                pair_rows(ua, ub, hk, gk, w0, (63u - lh) * 4u, regs);
+                pair_rows(ua, ub, he, he + N2, tw_bin[64 * ra + lh], (63u - lh) * 4u, regs);
             }
             // ---- second transform: rows, stage factors, radix-K1 sum ----
             asm volatile("" : "+v"(la));
-            if (!(a.prefetch & 1)) row_passes_512(ua, wreg, tw1, tw2, la);
+            row_passes_512(ua, wreg, tw1, tw2, la);
             asm volatile("" : "+v"(lb));
-            if (!(a.prefetch & 1)) row_passes_512(ub, wreg, tw1, tw2, lb);
+            row_passes_512(ub, wreg, tw1, tw2, lb);
         }
         {
             unsigned t2 = tl;
@@ -1875,26 +1843,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             __syncthreads();
         }
-        if (!(a.prefetch & 4)) {
         sf.apply(v);
         dft_reg<K1, 1>(v);
-        }
 
-        // sample m = 2n (+1) of the block is output m - (nh-1) of it; the result comes out
+        // sample m = 2n (+1) of the block is output m - ov of it; the result comes out
         // swapped: im is the even sample, re the odd one
         unsigned to = tl;
         asm volatile("" : "+v"(to) : "v"(v[0].re));
         float *yrow = a.y + c * a.y_stride;
         if (interior) {
-            C<T> *q0 = reinterpret_cast<C<T> *>(yrow + ((a.prefetch & 16) ? (long)M * (blockIdx.x & 7) : base)) + to;
-            const int skip = (int)(nh - 1) / 2 - (int)to;  // element offsets below this are overlap
+            C<T> *q0 = reinterpret_cast<C<T> *>(yrow + base) + to;
+            const int skip = (int)ov / 2 - (int)to;  // element offsets below this are overlap
 #pragma unroll
             for (int n1 = 0; n1 < K1; n1++)
                 if (NS * n1 >= skip) nt_store(C<T>{v[n1].im, v[n1].re}, q0 + NS * n1);
         } else {
 #pragma unroll
             for (int n1 = 0; n1 < K1; n1++) {
-                const long j = 2 * (long)(to + NS * n1) - (nh - 1);
+                const long j = 2 * (long)(to + NS * n1) - ov;
                 const long o0 = (long)blk * L + j;
                 if (j >= 0 && o0 < nx) yrow[o0] = v[n1].im;
                 if (j + 1 >= 0 && o0 + 1 < nx) yrow[o0 + 1] = v[n1].re;
@@ -1918,24 +1884,19 @@ int launch_ols_real(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
     OlsArgs a;
     a.x = o.x; a.hist = o.hist; a.y = o.y; a.H = static_cast<const C<float> *>(o.H);
     a.x_stride = o.x_stride; a.y_stride = o.y_stride; a.hist_stride = o.hist_stride;
-    a.nx = o.nx; a.nh = o.nh; a.L = M - (o.nh - 1);
+    a.nx = o.nx; a.nh = o.nh; a.L = M - (o.nh & ~1u);  // an even overlap: nh-1, or nh
     a.nblk = (unsigned)(((unsigned long long)o.nx + a.L - 1) / a.L);
     a.npair = a.nblk;
     a.nchan = o.nchan;
     const size_t total = (size_t)a.nchan * a.nblk;
     if (total == 0) return DSPMI_OK;
-    size_t grid = total < (size_t)2 * num_cu ? total : (size_t)2 * num_cu;
+    // One block per workgroup, two workgroups per CU at a time: the dispatcher hands a CU its next
+    // block the moment one is finished, which evens out what a fixed walk leaves to the last round
+    // (2731 blocks of 2^26 samples with rotating buffers: 0.224 ms with a resident set of 512
+    // workgroups walking the blocks, 0.218 with four times that, 0.209 with one block each).
+    size_t grid = total < 0x7fffffffu ? total : 0x7fffffffu;
     if (const char *g = getenv("DSPMI_OLS_GRID"))  // tests: few workgroups, so that short signals make each walk several blocks
         if (atoi(g) > 0 && (size_t)atoi(g) < grid) grid = (size_t)atoi(g);
-    {
-        const char *env = getenv("DSPMI_OLS_STAGGER");
-        a.stagger = env ? (unsigned)atoi(env) : 0u;
-        if (grid < (size_t)2 * num_cu) a.stagger = 0;
-        if (const char *all = getenv("DSPMI_OLS_STAGGER_ALL")) a.stagger_all = (unsigned)atoi(all);
-        if (const char *w = getenv("DSPMI_OLS_WHATIF")) a.prefetch = (unsigned)atoi(w);
-    }
-    if (const char *g = getenv("DSPMI_OLS_GRIDX"))  // experiment: resident set times this
-        if (atoi(g) > 0) grid = total < (size_t)atoi(g) * num_cu ? total : (size_t)atoi(g) * num_cu;
     // tables: exp(-2 pi i k / 512), k < 512; the stage factors [K1][512]; the bin factors [K1][64]
     const C<float> *tw_sub = static_cast<const C<float> *>(tables);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, s, a, tw_sub, tw_sub + NS, tw_sub + NS + N2);

@@ -144,10 +144,54 @@ def test_fused_kernels_agree_with_the_five_kernel_composition(nh, fft_n, monkeyp
         check_blocks(b[c], want[c], x[c], h, ("composed", nh, fft_n, c))
 
 
+@pytest.mark.parametrize("nh,nx,nchan,with_hist", [(8191, 150000, 2, False), (8191, 70001, 3, True), (8192, 90000, 2, True),
+                                                   (2049, 100000, 2, True), (16, 40000, 2, False), (16384, 120001, 1, True),
+                                                   (5000, 3 * 27769, 2, False), (8191, 1, 1, False), (8191, 8190, 1, True)])
+@pytest.mark.parametrize("grid", [0, 3])
+def test_long_blocks_one_real_block_per_transform(nh, nx, nchan, with_hist, grid, monkeypatch):
+    """32768-sample blocks run one real block through a 16384-point complex transform (even samples
+    as real parts, odd samples as imaginary parts; the default), or two blocks through a
+    32768-point transform (DSPMI_OLS_REAL=0).  Both against the oracle per 4096-sample block where
+    it can be swept, and against each other: odd and even tap counts (an even count starts blocks
+    on odd samples, which takes the kernel's element-by-element path, as do rows of odd stride),
+    carried history, ragged ends, rows shorter than the filter, a single sample; with one block
+    per workgroup and with three workgroups walking all blocks (DSPMI_OLS_GRID)."""
+    rng = np.random.default_rng(nh + nx + grid)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32) if with_hist else None
+    xd = torch.from_numpy(x).cuda()
+    hd = torch.from_numpy(hist).cuda() if with_hist else None
+    one = dsp_amd.OlsPlan(h, 32768)
+    monkeypatch.setenv("DSPMI_OLS_REAL", "0")
+    two = dsp_amd.OlsPlan(h, 32768)
+    monkeypatch.delenv("DSPMI_OLS_REAL")
+    if grid:
+        monkeypatch.setenv("DSPMI_OLS_GRID", str(grid))
+    a = one.exec(xd, hist=hd).cpu().numpy()
+    b = two.exec(xd, hist=hd).cpu().numpy()
+    scale = np.linalg.norm(h.astype(np.float64)) * np.linalg.norm(x.astype(np.float64), axis=1)
+    for c in range(nchan):
+        # two roundings apart at most: each is within 1e-6 of the double sum
+        assert np.linalg.norm(a[c].astype(np.float64) - b[c]) <= 2 * TOL_FIR * max(scale[c], np.linalg.norm(b[c].astype(np.float64)))
+    if nh <= 8192:
+        full = np.concatenate([hist, x], axis=1) if with_hist else x
+        want = oracle.fir_batch_f32(full, h, full.shape[1])[:, full.shape[1] - nx:]
+        for c in range(nchan):
+            if with_hist:
+                # every block is steady state once the history is there: hold all of them to the block bound
+                for lo in range(0, nx, BLK):
+                    w = want[c, lo:lo + BLK]
+                    assert np.linalg.norm(a[c, lo:lo + BLK] - w) <= TOL_FIR * np.linalg.norm(w), (nh, nx, c, lo)
+            else:
+                check_blocks(a[c], want[c], x[c], h, (nh, nx, c))
+
+
 @pytest.mark.parametrize("nh", [2049, 8191, 16384])
 @pytest.mark.parametrize("grid", [1, 4, 7])
 def test_long_blocks_with_the_next_pair_requested_early(nh, grid, monkeypatch):
-    """32768-point blocks, few workgroups (DSPMI_OLS_GRID) so that each walks several block pairs:
+    """The kernel that runs block pairs (DSPMI_OLS_REAL=0).
+    32768-point blocks, few workgroups (DSPMI_OLS_GRID) so that each walks several block pairs:
     from its second interior pair on a workgroup takes its input from the requests it issued
     ahead of the previous pair's stores (even block through LDS, odd block through registers).
     Checked against the oracle per block, and bit for bit against the same launch with the early
@@ -160,6 +204,7 @@ def test_long_blocks_with_the_next_pair_requested_early(nh, grid, monkeypatch):
     x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
     hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
     xd, hd = torch.from_numpy(x).cuda(), torch.from_numpy(hist).cuda()
+    monkeypatch.setenv("DSPMI_OLS_REAL", "0")
     plan = dsp_amd.OlsPlan(h, 32768)
     monkeypatch.setenv("DSPMI_OLS_GRID", str(grid))
     early = plan.exec(xd, hist=hd).cpu().numpy()

@@ -17,20 +17,21 @@ def main():
     axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[1:]]
     nh, nx = 8191, 1 << 26
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
-    xd = torch.rand((1, nx), device="cuda") * 2 - 1
-    y = torch.empty_like(xd)
+    nbuf = int(os.environ.get("NBUF", "1"))   # rotate over this many input / output pairs (beyond the last-level cache)
+    xs = [torch.rand((1, nx), device="cuda") * 2 - 1 for _ in range(nbuf)]
+    ys = [torch.empty_like(xs[0]) for _ in range(nbuf)]
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(2):
         for combo in itertools.product(*[v for _, v in axes]):
             for (k, _), v in zip(axes, combo):
                 os.environ[k] = v
             pl = dsp_amd.OlsPlan(h, 32768)
-            for _ in range(80):
-                pl.exec(xd, y=y)
+            for i in range(80):
+                pl.exec(xs[i % nbuf], y=ys[i % nbuf])
             torch.cuda.synchronize()
             ev0.record()
-            for _ in range(60):
-                pl.exec(xd, y=y)
+            for i in range(60):
+                pl.exec(xs[i % nbuf], y=ys[i % nbuf])
             ev1.record()
             torch.cuda.synchronize()
             ms = ev0.elapsed_time(ev1) / 60
