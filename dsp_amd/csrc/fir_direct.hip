@@ -784,6 +784,7 @@ struct dspmi_fir_plan {
     // kernel from about 64 taps, the f16 kernel from about 310
     dspmi_ols_t ols = nullptr;
     unsigned ols_n = 0;
+    dspmi_ols_t ols_long = nullptr;  // 32768-sample blocks beside a shorter transform: rows of 65536 samples and more
     // f32 plans of up to 32 * kSplitMaxSlices - 15 taps: the tap matrix of the bf16 kernel, as
     // [slice][part][lane] register images, and its slice count
     void *split_tab = nullptr;
@@ -1074,6 +1075,7 @@ constexpr int kTapPad = 16;   // taps are padded to a multiple of this (>= every
 // against 1.03 for overlap-save and 0.98 for the bf16 kernel; 305 taps 1.09 against 1.16 for
 // overlap-save).
 constexpr unsigned kSplitAutoMinTaps = 33;
+constexpr unsigned kOlsLongMinTaps = 900;
 constexpr unsigned kOlsMinTaps = 64;  // measured crossover (direct 1.12 ms vs 1.08 at 64 taps; direct wins below)
 constexpr int kSeg = 2048;    // taps per LDS staging round
 
@@ -1161,11 +1163,21 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
                 if (nh > 2048) n = 0;
                 if (dspmi_ols_create_f32(&pl->ols, taps, nh, n, device) == DSPMI_OK) pl->ols_n = dspmi_ols_fft_length(pl->ols);
                 else pl->ols = nullptr;
+                // From about 900 taps the kernel that runs one 32768-sample block per 16384-point
+                // transform is ahead of the shorter transforms on rows that fill a few such blocks
+                // (512 x 2^20 samples: 1024 taps 1.31 ms against 1.36 with 4096-point blocks, 1536
+                // taps 1.32 against 1.53, 2048 taps 1.34 against 1.73); shorter rows keep the
+                // shorter transform.
+                const char *real = getenv("DSPMI_OLS_REAL");
+                if (pl->ols && nh >= kOlsLongMinTaps && nh <= 2048 && !(real && !atoi(real)) &&
+                    dspmi_ols_create_f32(&pl->ols_long, taps, nh, 32768, device) != DSPMI_OK)
+                    pl->ols_long = nullptr;
             }
         }
     }
     if (pl->half_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_f16x2_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
+    else if (pl->ols_long) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u_or_n32768", pl->ols_n);
     else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
     else snprintf(pl->name, sizeof pl->name, "%s", kVariantName[pl->variant]);
     *out = pl;
@@ -1193,6 +1205,8 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     if constexpr (sizeof(T) == 4) {
         // overlap-save covers the plain case: as many outputs as inputs, rows long enough to
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
+        if (pl->ols_long && flags == 0 && nxx == nx && nx >= 2 * 32768)
+            return dspmi_ols_exec_f32(pl->ols_long, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
         if (pl->ols && flags == 0 && nxx == nx && nx >= 2 * pl->ols_n)
             return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
         if (pl->half_tab && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
@@ -1257,6 +1271,7 @@ int dspmi_fir_destroy(dspmi_fir_t plan)
 {
     if (!plan) return DSPMI_OK;
     if (plan->ols) (void)dspmi_ols_destroy(plan->ols);
+    if (plan->ols_long) (void)dspmi_ols_destroy(plan->ols_long);
     (void)hipFree(plan->split_tab);
     (void)hipFree(plan->half_tab);
     hipError_t e = hipFree(plan->taps_dev);

@@ -125,6 +125,26 @@ def test_fir_plan_takes_the_long_block_path_with_history(nh):
         check_blocks(got[c], want[c], x[c], h, (nh, c))
 
 
+@pytest.mark.parametrize("nh", [900, 1024, 2048])
+def test_fir_plan_of_a_thousand_taps_by_row_length(nh):
+    """From 900 to 2048 taps an f32 FIR plan holds two overlap-save plans: rows of 65536 samples
+    and more go through 32768-sample blocks, shorter rows through the shorter transform; both
+    with carried history against the oracle."""
+    rng = np.random.default_rng(nh)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert plan.variant.startswith("fir_f32_overlap_save_n") and plan.variant.endswith("_or_n32768")
+    for nchan, chunk in ((2, 70001), (3, 30000)):
+        x = rng.uniform(-1, 1, (nchan, 2 * chunk)).astype(np.float32)
+        xd = torch.from_numpy(x).cuda()
+        first = plan.exec(xd[:, :chunk].contiguous())
+        second = plan.exec(xd[:, chunk:].contiguous(), hist=xd[:, chunk - (nh - 1):chunk].contiguous())
+        got = torch.cat([first, second], dim=1).cpu().numpy()
+        want = oracle.fir_batch_f32(x, h, 2 * chunk)
+        for c in range(nchan):
+            check_blocks(got[c], want[c], x[c], h, (nh, chunk, c))
+
+
 @pytest.mark.parametrize("nh,fft_n", [(127, 1024), (1000, 4096), (8191, 16384), (8191, 32768)])
 def test_fused_kernels_agree_with_the_five_kernel_composition(nh, fft_n, monkeypatch):
     """DSPMI_OLS_COMPOSED=1 runs the same arithmetic as five kernels through HBM (gather, batched
