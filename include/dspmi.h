@@ -220,7 +220,11 @@ const char *dspmi_fft_variant(dspmi_fft_t plan);
  * doc/notes:81-82) applied to overlapping blocks.  A plan holds H = FFT(taps)/N. */
 typedef struct dspmi_ols_plan *dspmi_ols_t;
 
-/* fft_n: transform length (power of two >= 2*nh, <= 32768), or 0 to choose. */
+/* fft_n: block length in samples (power of two >= 2*nh, <= 32768), or 0 to choose.  Up to
+ * 16384 two real blocks ride one fft_n-point complex transform; a 32768-sample block rides a
+ * 16384-point transform on its own (even samples as real parts, odd samples as imaginary parts),
+ * the default beyond 2048 taps.  DSPMI_OLS_REAL=0 in the environment at creation selects the
+ * kernel that runs pairs of 32768-sample blocks through 32768-point transforms instead. */
 int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsigned fft_n, int device);
 int dspmi_ols_destroy(dspmi_ols_t plan);
 unsigned dspmi_ols_fft_length(dspmi_ols_t plan);
