@@ -1,8 +1,10 @@
-"""Randomised check of the 32768-point overlap-save kernel: tap counts 2049..16384, row lengths, channel
-counts, history, few or many workgroups (DSPMI_OLS_GRID), start-time spread on and off.  Each case is run
-with the next pair's input requested early and without (DSPMI_OLS_PREFETCH=0): the outputs must be equal
-bit for bit; every fourth case is also held to the five-kernel composition (DSPMI_OLS_COMPOSED=1) within
-the FIR bound.  usage: python tools/ols_fuzz.py [seconds] [seed]"""
+"""Randomised check of the two overlap-save kernels for 32768-sample blocks: tap counts 2..16384, row
+lengths, channel counts, history, few or many workgroups (DSPMI_OLS_GRID).  Half the cases run the kernel
+with one real block per transform (the default) and are held to the five-kernel composition
+(DSPMI_OLS_COMPOSED=1) within the FIR bound; the others run the block-pair kernel (DSPMI_OLS_REAL=0), start-time
+spread on and off, with the next pair's input requested early and without (DSPMI_OLS_PREFETCH=0): those
+outputs must be equal bit for bit, and every fourth is also held to the composition.
+usage: python tools/ols_fuzz.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -20,7 +22,8 @@ t0 = time.time()
 ncase = 0
 worst = 0.0
 while time.time() - t0 < budget:
-    nh = int(rng.choice([2049, 4096, 8191, 16384, rng.integers(2049, 16385)]))
+    real = bool(rng.integers(0, 2))
+    nh = int(rng.choice([2049, 4096, 8191, 16384, rng.integers(2049, 16385), rng.integers(2, 2049)]))
     L = 32768 - (nh - 1)
     npairs = int(rng.integers(1, 14))
     nx = int(max(1, 2 * npairs * L - rng.integers(0, 2 * L)))
@@ -30,7 +33,9 @@ while time.time() - t0 < budget:
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     x = torch.from_numpy(rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)).cuda()
     hist = torch.from_numpy(rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)).cuda() if use_hist else None
+    os.environ["DSPMI_OLS_REAL"] = "1" if real else "0"
     plan = dsp_amd.OlsPlan(h, 32768)
+    del os.environ["DSPMI_OLS_REAL"]
     os.environ["DSPMI_OLS_GRID"] = str(grid)
     os.environ["DSPMI_OLS_STAGGER"] = str(int(rng.choice([0, 60000])))
     os.environ.pop("DSPMI_OLS_PREFETCH", None)
@@ -42,7 +47,7 @@ while time.time() - t0 < budget:
         bad = np.argwhere(early != plain)
         print("FAIL: early requests change the output", dict(nh=nh, nx=nx, nchan=nchan, grid=grid, hist=use_hist, first=bad[0].tolist(), count=len(bad)), flush=True)
         sys.exit(1)
-    if ncase % 4 == 0:
+    if real or ncase % 4 == 0:
         os.environ["DSPMI_OLS_COMPOSED"] = "1"
         ref = dsp_amd.OlsPlan(h, 32768)
         del os.environ["DSPMI_OLS_COMPOSED"]
@@ -53,7 +58,7 @@ while time.time() - t0 < budget:
                 err = np.linalg.norm(early[c, a:a + 4096] - w)
                 lim = 1e-6 * max(np.linalg.norm(w), np.linalg.norm(h) * np.sqrt(len(w) / 3.0))
                 if err > lim:
-                    print("FAIL: differs from the five-kernel composition", dict(nh=nh, nx=nx, nchan=nchan, grid=grid, chan=c, block=a, err=err, lim=lim), flush=True)
+                    print("FAIL: differs from the five-kernel composition", dict(real=real, nh=nh, nx=nx, nchan=nchan, grid=grid, hist=use_hist, chan=c, block=a, err=err, lim=lim), flush=True)
                     sys.exit(1)
                 worst = max(worst, err / lim)
     ncase += 1
