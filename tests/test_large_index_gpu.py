@@ -20,7 +20,9 @@ def rel_l2(got, want):
                                         (127, "f16", (1 << 31) + 5000),
                                         # the longest row the 32-bit sample count can express
                                         (127, "overlap_save", (1 << 32) - 3), (16, "direct", (1 << 32) - 3),
-                                        (127, "f16", (1 << 32) - 3)])
+                                        (127, "f16", (1 << 32) - 3),
+                                        # 32768-sample blocks, one per 16384-point transform
+                                        (8191, "overlap_save", (1 << 31) + 5000), (8191, "overlap_save", (1 << 32) - 3)])
 def test_fir_row_longer_than_2_31_samples(nh, path, nx, monkeypatch):
     if torch.cuda.mem_get_info()[0] < 60 << 30:
         pytest.skip("needs 60 GiB of free device memory")
