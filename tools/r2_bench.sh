@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 measurement pass: default bench, the same under rocprofv3 --kernel-trace --stats,
+# Measurement pass: default bench, the same under rocprofv3 --kernel-trace --stats,
 # the HBM-traffic counter passes for the 8191-tap overlap-save kernel, and a 2-rank rehearsal of
 # the split-signal workload (gloo; both ranks on the one GPU).  Usage: tools/r2_bench.sh <tag>
 set -o pipefail
