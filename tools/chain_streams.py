@@ -1,6 +1,6 @@
 """The chain (tones -> 127-tap FIR + 4096-point spectrum) with the generator of chunk k+1 on a
 second stream beside the filter + spectrum kernel of chunk k (two sample buffers), against the
-same launches in one stream.  usage: python tools/chain_streams.py [priority of the generator's stream: 0 or -1]"""
+same launches in one stream.  usage: python tools/chain_streams.py [priority of the generator's stream: 0 or -1] [chunks]"""
 import os
 import sys
 
@@ -14,7 +14,8 @@ import oracle   # noqa: E402
 
 def main():
     prio = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    nchan, nfft, nchunk, nh = 1024, 4096, 4, 127
+    nchan, nfft, nh = 1024, 4096, 127
+    nchunk = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     chunk = (1 << 20) // nchunk
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     freqs = np.array([[100.0 * (c + 1), 12000.0] for c in range(nchan)])
@@ -60,7 +61,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / 10
-        print("%s (generator priority %d): %.3f ms per step, %.1f Gsamples/s" % (name, prio, ms, nchan * (1 << 20) / ms / 1e6), flush=True)
+        print("%s (generator priority %d, %d chunks): %.3f ms per step, %.1f Gsamples/s" % (name, prio, nchunk, ms, nchan * (1 << 20) / ms / 1e6), flush=True)
 
 
 if __name__ == "__main__":
