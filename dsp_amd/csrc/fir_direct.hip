@@ -778,6 +778,7 @@ struct dspmi_fir_plan {
     unsigned nh, nhp;
     void *taps_dev;
     int variant;  // index into the table below
+    bool pinned = false;  // DSPMI_FIR_VARIANT named the kernel: no other is substituted
     std::vector<double> taps_host;
     // f32 plans beyond the 16-bit kernels' tap counts also hold an overlap-save plan: the same
     // outputs through FFTs cost fewer flops than 2*nh per sample (doc/notes:81-82) and beat the f32
@@ -850,6 +851,98 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
     }
     hipLaunchKernelGGL(seg <= 256 ? k_small : k_large, dim3(blocks), dim3(256), lds, stream, p);
     DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// up to 16 taps as a plain stream: no tiles, no LDS
+// ---------------------------------------------------------------------------
+
+// A filter this short is a copy with a few multiply-adds on the way.  The tile kernels above
+// load a tile, then store a tile; the fastest copy on this chip is the simplest one -- one
+// 16-byte element per thread, a grid that covers the array.  Here a thread takes four consecutive
+// outputs: it loads its own four samples and the sixteen before them as five aligned 16-byte
+// loads (four of the five are what lower-numbered lanes of the same wave load as well: cache
+// hits), sums sixteen products per output with the taps in scalar registers, and stores 16 bytes.
+// The first four threads of a row (history or zeros before the row) and the last one of a row
+// whose length is not a multiple of four go element by element.
+// Requires nxx == nx, no flags, rows that start on 16-byte boundaries.  512 x 2^20 samples, 16 taps:
+// 0.732 ms against 0.752 for the tile kernel on the same box (5.88 against 5.72 TB/s); eight or
+// sixteen outputs per thread are slower (0.806, 1.50 ms: a lane's accesses are then 32 or 64 bytes apart).
+__global__ __launch_bounds__(256) void fir_stream16_kernel(const FirParams<float> p, unsigned rows_per_y)
+{
+    const size_t row = (size_t)blockIdx.y + (size_t)rows_per_y * blockIdx.z;
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;  // which four outputs of the row
+    const size_t i0 = (size_t)q * 4;
+    if (i0 >= p.nx) return;
+    float h[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) h[j] = p.taps[j];  // uniform: scalar loads (zero-padded past nh)
+    const float *x = p.x + row * p.x_stride;
+    float *y = p.y + row * p.y_stride;
+    float w[20];
+    const bool whole = q >= 4 && i0 + 4 <= p.nx;
+    if (whole) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + i0 - 16);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const f32x4 v = src[k];
+            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+        }
+    } else {
+        const float *hist = p.hist ? p.hist + row * p.hist_stride : nullptr;
+        const long nh = p.nh;
+#pragma unroll
+        for (int k = 0; k < 20; k++) {
+            const long s = (long)i0 - 16 + k;
+            w[k] = s >= 0 ? (s < (long)p.nx ? x[s] : 0.f) : (hist && s >= 1 - nh ? hist[nh - 1 + s] : 0.f);
+        }
+    }
+    float acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 15; j >= 0; j--) a = __builtin_fmaf(h[j], w[16 + o - j], a);  // descending tap index, as the tile kernel sums
+        acc[o] = a;
+    }
+    if (whole) {
+        const f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(y + i0));
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+            if (i0 + o < p.nx) y[i0 + o] = acc[o];
+    }
+}
+
+// nullptr-safe test of what the stream kernel needs; the caller falls back to the tile kernel otherwise
+bool stream16_applies(const FirParams<float> &p)
+{
+    const char *env = getenv("DSPMI_FIR_STREAM");  // 0: keep the tile kernel (A/B)
+    if (env && !atoi(env)) return false;
+    return p.nh <= 16 && p.nhp >= 16 && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & 3) && !(p.y_stride & 3) &&
+           !((reinterpret_cast<size_t>(p.x) | reinterpret_cast<size_t>(p.y)) & 15);
+}
+
+int launch_stream16(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
+{
+    const unsigned quads = (unsigned)(((unsigned long long)p.nx + 3) / 4);
+    const unsigned gx = (quads + 255) / 256;
+    const unsigned gy = nchan < 65535u ? nchan : 65535u;
+    // rows beyond 65535 go into the grid's third dimension; the remainder is a second launch
+    const unsigned gz = nchan / gy;
+    hipLaunchKernelGGL(fir_stream16_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, p, gy);
+    DSPMI_HIP(hipGetLastError());
+    const unsigned done = gy * gz;
+    if (done < nchan) {
+        FirParams<float> r = p;
+        r.x += (size_t)done * p.x_stride;
+        r.y += (size_t)done * p.y_stride;
+        if (r.hist) r.hist += (size_t)done * p.hist_stride;
+        hipLaunchKernelGGL(fir_stream16_kernel, dim3(gx, nchan - done, 1), dim3(256), 0, stream, r, nchan - done);
+        DSPMI_HIP(hipGetLastError());
+    }
     return DSPMI_OK;
 }
 
@@ -1135,6 +1228,7 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         const bool want_bf16 = env && !strcmp(env, "bf16"), want_ols = env && !strcmp(env, "ols");
         const bool want_half = !want_bf16, want_split = want_bf16 || (env && !strcmp(env, "f16"));
         pl->variant = valu ? (nh <= 32 ? V_F32_SHORT : V_F32_LONG) : V_F32_MFMA;
+        pl->pinned = valu || mfma;
         if constexpr (sizeof(T) == 4) {
             const unsigned split_max = 32 * kSplitMaxSlices - 15;
             if (!valu && !mfma && !want_ols && nh >= (want_split ? 1u : kSplitAutoMinTaps) && nh <= split_max) {
@@ -1179,6 +1273,8 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
     else if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->ols_long) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u_or_n32768", pl->ols_n);
     else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
+    else if (precision == DSPMI_F32 && pl->variant == V_F32_MFMA && !pl->pinned && nh <= 16)
+        snprintf(pl->name, sizeof pl->name, "fir_f32_stream16");  // (calls it does not cover run the matrix kernel)
     else snprintf(pl->name, sizeof pl->name, "%s", kVariantName[pl->variant]);
     *out = pl;
     return DSPMI_OK;
@@ -1212,6 +1308,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         if (pl->half_tab && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
+            if (!pl->pinned && stream16_applies(p)) return launch_stream16(p, nchan, s);
             return launch_mfma(p, nchan, s);
         }
         if (pl->variant == V_F32_SHORT) {

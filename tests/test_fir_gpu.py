@@ -479,3 +479,49 @@ def test_split_kernels_degenerate_shapes(monkeypatch, split_kind):
     want = oracle.fir_batch_f32(np.concatenate([hist, x], axis=1), h, nh - 1 + 5)[:, nh - 1:]
     for c in (0, 1, 1999, 3999):
         assert_blocks(got[c], want[c], h, np.concatenate([hist[c], x[c]]), c)
+
+
+@pytest.mark.parametrize("nh", [1, 5, 16])
+@pytest.mark.parametrize("nx,nchan,stride_pad", [(64, 1, 0), (65, 3, 3), (4099, 3, 1), (100000, 2, 0), (100002, 2, 2)])
+@pytest.mark.parametrize("with_hist", [False, True])
+def test_short_filters_as_a_stream(nh, nx, nchan, stride_pad, with_hist, monkeypatch):
+    """Up to 16 taps an f32 plan runs calls with as many outputs as inputs on 16-byte aligned rows
+    through a kernel without tiles (four outputs per thread straight from global memory); other
+    calls, and DSPMI_FIR_STREAM=0, run the matrix kernel.  Both against the oracle per row, and
+    against each other: row lengths that are not multiples of four, padded strides, history."""
+    rng = np.random.default_rng(nh * 1000 + nx)
+    h = (oracle.windowed_sinc_taps(nh) if nh > 1 else np.array([0.75])).astype(np.float32)
+    stride = nx + stride_pad
+    if stride % 4:
+        stride += 4 - stride % 4          # rows start on 16-byte boundaries
+    buf = torch.zeros((nchan, stride), dtype=torch.float32, device="cuda")
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    buf[:, :nx] = torch.from_numpy(x).cuda()
+    xd = buf[:, :nx]
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32) if with_hist and nh > 1 else None
+    hd = None if hist is None else torch.from_numpy(hist).cuda()
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert plan.variant == "fir_f32_stream16"
+    ybuf = torch.zeros((nchan, stride), dtype=torch.float32, device="cuda")
+    a = plan.exec(xd, nx, y=ybuf[:, :nx], hist=hd).cpu().numpy().copy()
+    monkeypatch.setenv("DSPMI_FIR_STREAM", "0")
+    b = plan.exec(xd, nx, y=ybuf[:, :nx], hist=hd).cpu().numpy().copy()
+    full = x if hist is None else np.concatenate([hist, x], axis=1)
+    want = oracle.fir_batch_f32(full, h, full.shape[1])[:, full.shape[1] - nx:]
+    for c in range(nchan):
+        assert rel_l2(a[c], want[c]) <= TOL_FIR, (nh, nx, c, rel_l2(a[c], want[c]))
+        assert rel_l2(b[c], want[c]) <= TOL_FIR
+        assert rel_l2(a[c], b[c]) <= TOL_FIR
+
+
+def test_short_filter_stream_over_many_rows():
+    """More rows than one grid dimension holds (65535): the rest goes into a second launch."""
+    nh, nx, nchan = 16, 64, 70001
+    rng = np.random.default_rng(3)
+    h = np.asarray(oracle.TAPS16, dtype=np.float32)
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    y = plan.exec(torch.from_numpy(x).cuda(), nx).cpu().numpy()
+    for c in (0, 1, 65534, 65535, 65536, 70000):
+        want = oracle.fir_batch_f32(x[c:c + 1], h, nx)[0]
+        assert rel_l2(y[c], want) <= TOL_FIR, c
