@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
     ap.add_argument("--long-samples", type=int, default=1 << 26, help="samples of the single long signal (8191-tap workloads)")
+    ap.add_argument("--chain-taps", type=int, default=127, choices=[16, 127], help="chain workload: the 16-tap table of alsa/main.c or the 127-tap low-pass")
     ap.add_argument("--chunks", type=int, default=4, help="chain workload: chunks the 2^20 samples per channel are streamed in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -276,8 +277,8 @@ def make_chain(args, rank):
     FIR + FFT stages alone (tones pre-generated) is reported beside it."""
     nchan, nfft, nchunk = 1024, 4096, args.chunks
     chunk = (1 << 20) // nchunk
-    nh = 127
-    taps = sinc_taps(nh)
+    nh = args.chain_taps
+    taps = TAPS16 if nh == 16 else sinc_taps(nh)
     freqs = np.array([[100.0 * (c + 1 + 1024 * rank), 12000.0] for c in range(nchan)])
     gen = dsp_amd.ToneGen(48000.0, freqs, use_sin=True)
     fir = dsp_amd.FirPlan(taps, "f32")
@@ -287,7 +288,7 @@ def make_chain(args, rank):
     ps = torch.empty((nchan * chunk // nfft, nfft // 2 + 1), dtype=torch.float32, device="cuda")
     hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
 
-    fused = "f16x2" in fir.variant and not args.chain_two_kernels
+    fused = nh <= 305 and not args.chain_two_kernels
 
     def filter_and_transform():
         if fused:
@@ -313,7 +314,7 @@ def make_chain(args, rank):
     fir_fft_ms = (time.perf_counter() - t0) * 1e3 / 3
 
     units = nchan * chunk * nchunk
-    info = dict(kernel=("tonegen + fir_spectrum(%s, n%d)" % (fir.variant, nfft)) if fused else
+    info = dict(kernel=("tonegen + fir_spectrum(f16x2 matrix pipe, %d taps, n%d)" % (nh, nfft)) if fused else
                 "tonegen + %s + r2c_spectrum(%s)" % (fir.variant, fft.variant), units=units, unit_name="samples",
                 nh=nh, flop_per_unit=2.0 * nh + 2.5 * math.log2(nfft), bytes_per_unit=4.0 + 2.0, bound="hbm",
                 samples_per_unit=1, fir_fft_ms=fir_fft_ms,
@@ -579,7 +580,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         del keep, fn
         torch.cuda.empty_cache()
-        jobs = [("fir", 16, False), ("fir", 127, False), ("fir", 127, True), ("ols8191",), ("fir8191",), ("chain",)]
+        jobs = [("fir", 16, False), ("fir", 127, False), ("fir", 127, True), ("ols8191",), ("fir8191",), ("chain", 127), ("chain", 16)]
         for job in jobs:
             if job[0] == "fir":
                 _, nh, direct = job
@@ -588,6 +589,7 @@ def main():
                 f2, i2, k2 = make_fir(args, rank, nh, direct)
                 nsec, nwarm = 20, 40
             elif job[0] == "chain":
+                args.chain_taps = job[1]
                 f2, i2, k2 = make_chain(args, rank)
                 nsec, nwarm = 10, 15
             else:

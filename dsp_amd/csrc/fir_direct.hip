@@ -792,6 +792,7 @@ struct dspmi_fir_plan {
     int split_ns = 0;
     // ... and of the f16 kernel, with the factor that undoes the scale the taps were split under
     void *half_tab = nullptr;
+    bool half_exec = false;  // dspmi_fir_exec_f32 runs the f16 kernel (shorter plans hold its tables for the fused filter + spectrum entry only)
     float half_unscale = 1.f;
     char name[48] = "";
 };
@@ -1231,7 +1232,11 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         pl->pinned = valu || mfma;
         if constexpr (sizeof(T) == 4) {
             const unsigned split_max = 32 * kSplitMaxSlices - 15;
-            if (!valu && !mfma && !want_ols && nh >= (want_split ? 1u : kSplitAutoMinTaps) && nh <= split_max) {
+            // (plans below the f16 kernel's own range hold its tap images too, for the fused filter +
+            // spectrum entry point; their FIR calls keep the f32 kernels)
+            const bool tables_only = !env && nh < kSplitAutoMinTaps;
+            if (!valu && !mfma && !want_ols && (nh >= (want_split ? 1u : kSplitAutoMinTaps) || tables_only) && nh <= split_max) {
+                pl->half_exec = !tables_only;
                 pl->split_ns = (int)((nh + 15 + 31) / 32);
                 const std::vector<unsigned short> img = want_half ? half_tap_images(taps, nh, pl->split_ns, &pl->half_unscale)
                                                                   : split_tap_images(taps, nh, pl->split_ns);
@@ -1248,7 +1253,7 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
                     return dspmi::fail(DSPMI_EIO, "fir_create: %s", hipGetErrorString(e));
                 }
             }
-            if (!valu && !mfma && !pl->split_tab && !pl->half_tab && nh >= kOlsMinTaps && nh <= 8192) {
+            if (!valu && !mfma && !pl->split_tab && !(pl->half_tab && pl->half_exec) && nh >= kOlsMinTaps && nh <= 8192) {
                 // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
                 // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384; beyond 2048
                 // taps the plan's own default (32768-point blocks)
@@ -1269,7 +1274,7 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
             }
         }
     }
-    if (pl->half_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_f16x2_mfma16x16x32_s%d", pl->split_ns);
+    if (pl->half_tab && pl->half_exec) snprintf(pl->name, sizeof pl->name, "fir_f32_f16x2_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->ols_long) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u_or_n32768", pl->ols_n);
     else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
@@ -1305,7 +1310,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
             return dspmi_ols_exec_f32(pl->ols_long, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
         if (pl->ols && flags == 0 && nxx == nx && nx >= 2 * pl->ols_n)
             return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
-        if (pl->half_tab && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
+        if (pl->half_tab && pl->half_exec && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
             if (!pl->pinned && stream16_applies(p)) return launch_stream16(p, nchan, s);
@@ -1341,7 +1346,7 @@ int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *
 {
     if (!plan) return fail(DSPMI_EINVAL, "null FIR plan");
     if (!plan->half_tab)
-        return fail(DSPMI_ENOSYS, "the FIR plan runs %s, not the f16 matrix kernel (33..305 taps, or DSPMI_FIR_VARIANT=f16)", plan->name);
+        return fail(DSPMI_ENOSYS, "the FIR plan runs %s and holds no tap images of the f16 matrix kernel (plans of up to 305 taps do, unless DSPMI_FIR_VARIANT pins another kernel)", plan->name);
     *images = plan->half_tab;
     *unscale = plan->half_unscale;
     *slices = plan->split_ns;

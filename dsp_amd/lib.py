@@ -171,7 +171,7 @@ class FirPlan:
     def spectrum(self, fft, x, hist=None, nbin=None, mode=0, scale=1.0, out=None):
         """Filter, then the normalised magnitude spectrum of every 4096 filtered samples, in one
         kernel (the filtered samples are never written): x [nchan, nx], nx a multiple of 4096,
-        fft an f32 FftPlan(4096) -> [nchan * nx / 4096, nbin].  Plans of 33..305 taps only."""
+        fft an f32 FftPlan(4096) -> [nchan * nx / 4096, nbin].  Plans of up to 305 taps."""
         import torch
         assert not self.f64 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
         nchan, nx = x.shape

@@ -273,7 +273,8 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
  * ps[c * (nx / 4096) + f][k], k < nbin, is the normalised magnitude spectrum (mode, scale as
  * above; nbin = 2048 or 2049) of filtered samples 4096 f .. 4096 f + 4095 of channel c, the
  * filtered samples being those of dspmi_fir_exec_f32(fir, ..., nxx = nx, hist) -- they are never
- * written to memory.  fir: an f32 plan that runs the f16 matrix kernel (33 .. 305 taps); fft:
+ * written to memory.  fir: an f32 plan of up to 305 taps (the filter runs on the f16 matrix pipe
+ * here whatever kernel the plan's own FIR calls take, with that kernel's properties); fft:
  * an f32 plan of 4096 points; nx a multiple of 4096.  DSPMI_ENOSYS for any other pair of plans:
  * the caller then makes the two calls. */
 int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode,
