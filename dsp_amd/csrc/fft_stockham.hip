@@ -1719,26 +1719,29 @@ __device__ __forceinline__ void pair_self(C<float> *u, const C<float> *he, const
 }
 
 template <int K1>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void ols_real_kernel(const OlsArgs a,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, K1 == 32 ? 4 : 6))) void ols_real_kernel(const OlsArgs a,
                                                                                                   const C<float> *__restrict__ tw_sub,
                                                                                                   const C<float> *__restrict__ tw_stage,
                                                                                                   const C<float> *__restrict__ tw_bin)
 {
     typedef float T;
     constexpr int NS = 512, NW = 8, N2 = K1 * NS, M = 2 * N2;
-    static_assert(K1 == 32, "sixteen pairs of rows over eight waves");
+    static_assert(K1 == 32 || K1 == 16, "K1 / 2 pairs of rows over eight waves");
+    constexpr int UPW = K1 / 16, RPW = 2 * UPW;  // pairs of rows, rows per wave
     constexpr std::integer_sequence<int, 0, 1, 2, 3, 4, 5, 6, 7> regs{};
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const unsigned tl = threadIdx.x, lane = tl & 63, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tl >> 6));
     float *img = reinterpret_cast<float *>(smem_raw);  // [K1][512], one component at a time
     C<T> *wreg = reinterpret_cast<C<T> *>(smem_raw) + (size_t)wave * padded_len(NS);
-    static_assert((size_t)NW * padded_len(NS) * sizeof(C<T>) <= (size_t)N2 * sizeof(float), "the waves' regions alias the image");
+    // the waves' regions alias the image; the row tables sit behind the larger of the two
+    constexpr size_t REGIONS = (size_t)NW * padded_len(NS) * sizeof(C<T>), IMG = (size_t)N2 * sizeof(float);
     const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
-    setup_lds_twiddles<T, NS, 512, 0, 8, 8, 8, 1>(smem_raw + (size_t)N2 * sizeof(float), tw_sub, tw1, tw2, tw3);
+    setup_lds_twiddles<T, NS, 512, 0, 8, 8, 8, 1>(smem_raw + (IMG > REGIONS ? IMG : REGIONS), tw_sub, tw1, tw2, tw3);
 
     // the rows of this wave: s = 0, 1 one pair, s = 2, 3 the other
-    const unsigned row[4] = {2 * wave, wave ? K1 - 2 * wave : K1 / 2, 2 * wave + 1, K1 - 1 - 2 * wave};
+    // (K1 = 32: pairs 2 wave and 2 wave + 1; K1 = 16: pair wave.  Pair 0 is rows 0 and K1 / 2.)
+    const unsigned row[4] = {UPW * wave, wave ? K1 - UPW * wave : K1 / 2, 2 * wave + 1, K1 - 1 - 2 * wave};
 
     const long nx = a.nx, nh = a.nh, L = a.L;
     const size_t total = (size_t)a.nchan * a.nblk;
@@ -1782,14 +1785,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         sf.load(tw_stage + tt);
         dft_reg<K1, 1>(v);
         sf.apply(v);
-        C<T> u[4][8];
+        C<T> u[RPW][8];
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
 #pragma unroll
             for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = comp ? v[k1].im : v[k1].re;
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int s = 0; s < RPW; s++)
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const float q = img[NS * row[s] + lane + 64 * r];
@@ -1799,7 +1802,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             __syncthreads();
         }
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
+        for (int pr = 0; pr < UPW; pr++) {
             C<T> *ua = u[2 * pr], *ub = u[2 * pr + 1];
             const unsigned ra = row[2 * pr], rb = row[2 * pr + 1];
             unsigned la = lane, lb = lane, lh = lane;
@@ -1831,7 +1834,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int s = 0; s < RPW; s++)
 #pragma unroll
                 for (int r = 0; r < 8; r++) img[NS * row[s] + lane + 64 * r] = comp ? u[s][r].im : u[s][r].re;
             __syncthreads();
@@ -1873,8 +1876,9 @@ template <int K1>
 int launch_ols_real(const dspmi::OlsLaunch &o, const void *tables, int num_cu, hipStream_t s)
 {
     constexpr int NS = 512, N2 = K1 * NS, M = 2 * N2;
-    constexpr size_t lds = (size_t)N2 * sizeof(float) + lds_twiddle_entries(2, 8, 8, 8, 1) * sizeof(C<float>);
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    constexpr size_t regions = (size_t)8 * padded_len(NS) * sizeof(C<float>), img = (size_t)N2 * sizeof(float);
+    constexpr size_t lds = (img > regions ? img : regions) + lds_twiddle_entries(2, 8, 8, 8, 1) * sizeof(C<float>);
+    static_assert((K1 == 32 ? 2 : 3) * lds <= 160 * 1024, "two workgroups per CU (three with 16 points per lane)");
     auto kern = ols_real_kernel<K1>;
     static dspmi::PerDeviceOnce attr;
     if (attr.pending()) {
@@ -2549,7 +2553,10 @@ bluestein_launch_fn bluestein_find(unsigned m, int precision)
     return nullptr;
 }
 
-ols_launch_fn ols_find_real(unsigned block) { return block == 32768 ? launch_ols_real<32> : nullptr; }
+ols_launch_fn ols_find_real(unsigned block)
+{
+    return block == 32768 ? launch_ols_real<32> : block == 16384 ? launch_ols_real<16> : nullptr;
+}
 
 ols_launch_fn ols_find(unsigned n)
 {

@@ -785,7 +785,7 @@ struct dspmi_fir_plan {
     // kernel from about 64 taps, the f16 kernel from about 310
     dspmi_ols_t ols = nullptr;
     unsigned ols_n = 0;
-    dspmi_ols_t ols_long = nullptr;  // 32768-sample blocks beside a shorter transform: rows of 65536 samples and more
+    dspmi_ols_t ols_16k = nullptr;   // 16384-sample blocks, one per transform: long filters on rows shorter than that
     // f32 plans of up to 32 * kSplitMaxSlices - 15 taps: the tap matrix of the bf16 kernel, as
     // [slice][part][lane] register images, and its slice count
     void *split_tab = nullptr;
@@ -1253,30 +1253,31 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
                     return dspmi::fail(DSPMI_EIO, "fir_create: %s", hipGetErrorString(e));
                 }
             }
-            if (!valu && !mfma && !pl->split_tab && !(pl->half_tab && pl->half_exec) && nh >= kOlsMinTaps && nh <= 8192) {
-                // transform length: the smallest power of two >= 4*nh, at least 1024 (measured:
-                // 127 and 255 taps are fastest at 1024, 511 at 2048), at most 16384; beyond 2048
-                // taps the plan's own default (32768-point blocks)
+            if (!valu && !mfma && !pl->split_tab && !(pl->half_tab && pl->half_exec) && nh >= kOlsMinTaps && nh <= 16384) {
+                const char *real = getenv("DSPMI_OLS_REAL");
+                const bool real_blocks = !(real && !atoi(real));  // 0: the kernels that run block pairs (A/B)
+                // Up to 899 taps: the smallest power of two >= 4*nh, at least 1024 (measured: 127 and
+                // 255 taps are fastest at 1024, 511 at 2048).  From 900 taps the kernels that run
+                // one real block per transform: 32768-sample blocks for rows of 65536 samples and
+                // more (512 x 2^20 samples: 1024 taps 1.31 ms against 1.36 with 4096-point pairs,
+                // 2048 taps 1.34 against 1.73), and 16384-sample blocks below that, where the direct
+                // kernel's cost per 4096-output tile grows with the tap count whatever the row length
+                // while a block costs the same for any filter (512 rows of 4096 samples, 8191 taps:
+                // 0.260 ms direct, 0.023 ms as one block each; 900 taps: 0.036 against 0.023).
                 unsigned n = 1024;
                 while (n < 4 * nh && n < 16384) n <<= 1;
-                if (nh > 2048) n = 0;
-                if (dspmi_ols_create_f32(&pl->ols, taps, nh, n, device) == DSPMI_OK) pl->ols_n = dspmi_ols_fft_length(pl->ols);
+                if (nh > 2048 || (nh >= kOlsLongMinTaps && real_blocks)) n = 32768;
+                if ((real_blocks || nh <= 8192) && dspmi_ols_create_f32(&pl->ols, taps, nh, n, device) == DSPMI_OK)
+                    pl->ols_n = dspmi_ols_fft_length(pl->ols);
                 else pl->ols = nullptr;
-                // From about 900 taps the kernel that runs one 32768-sample block per 16384-point
-                // transform is ahead of the shorter transforms on rows that fill a few such blocks
-                // (512 x 2^20 samples: 1024 taps 1.31 ms against 1.36 with 4096-point blocks, 1536
-                // taps 1.32 against 1.53, 2048 taps 1.34 against 1.73); shorter rows keep the
-                // shorter transform.
-                const char *real = getenv("DSPMI_OLS_REAL");
-                if (pl->ols && nh >= kOlsLongMinTaps && nh <= 2048 && !(real && !atoi(real)) &&
-                    dspmi_ols_create_f32(&pl->ols_long, taps, nh, 32768, device) != DSPMI_OK)
-                    pl->ols_long = nullptr;
+                if (pl->ols && n == 32768 && nh <= 8192 && real_blocks &&
+                    dspmi_ols_create_f32(&pl->ols_16k, taps, nh, 16384, device) != DSPMI_OK)
+                    pl->ols_16k = nullptr;
             }
         }
     }
     if (pl->half_tab && pl->half_exec) snprintf(pl->name, sizeof pl->name, "fir_f32_f16x2_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
-    else if (pl->ols_long) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u_or_n32768", pl->ols_n);
     else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
     else if (precision == DSPMI_F32 && pl->variant == V_F32_MFMA && !pl->pinned && nh <= 16)
         snprintf(pl->name, sizeof pl->name, "fir_f32_stream16");  // (calls it does not cover run the matrix kernel)
@@ -1306,10 +1307,14 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     if constexpr (sizeof(T) == 4) {
         // overlap-save covers the plain case: as many outputs as inputs, rows long enough to
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
-        if (pl->ols_long && flags == 0 && nxx == nx && nx >= 2 * 32768)
-            return dspmi_ols_exec_f32(pl->ols_long, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
-        if (pl->ols && flags == 0 && nxx == nx && nx >= 2 * pl->ols_n)
-            return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+        if (pl->ols && flags == 0 && nxx == nx) {
+            const unsigned long long work = (unsigned long long)nx * pl->nh;
+            if (nx >= 2 * pl->ols_n) return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+            if (pl->ols_16k && work >= 400000ull)
+                return dspmi_ols_exec_f32(pl->ols_16k, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+            if (!pl->ols_16k && pl->nh > 8192 && work >= 4000000ull)  // beyond 8192 taps only the 32768-sample blocks fit
+                return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+        }
         if (pl->half_tab && pl->half_exec && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
@@ -1373,7 +1378,7 @@ int dspmi_fir_destroy(dspmi_fir_t plan)
 {
     if (!plan) return DSPMI_OK;
     if (plan->ols) (void)dspmi_ols_destroy(plan->ols);
-    if (plan->ols_long) (void)dspmi_ols_destroy(plan->ols_long);
+    if (plan->ols_16k) (void)dspmi_ols_destroy(plan->ols_16k);
     (void)hipFree(plan->split_tab);
     (void)hipFree(plan->half_tab);
     hipError_t e = hipFree(plan->taps_dev);

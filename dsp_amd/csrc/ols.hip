@@ -191,7 +191,7 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
     std::vector<C32> tw(rows ? 1024 + (size_t)N : N), h(N, C32{0.f, 0.f});
     if (pl->real_blocks) {
         // ols_real_kernel (fft_stockham.hip): N2 = N/2 complex points as 32 rows of 512
-        const unsigned N2 = N / 2, K1 = 32, NS = 512;
+        const unsigned N2 = N / 2, NS = 512, K1 = N2 / NS;
         tw.assign((size_t)NS + N2 + K1 * 64, C32{0.f, 0.f});
         auto unit = [&](unsigned long long e, unsigned n) {
             const long double a = -two_pi * (long double)(e % n) / (long double)n;

@@ -80,8 +80,10 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  *                   each, under one power-of-two scale per 4096-output tile, accumulated in f32.
  *                   A sample more than 2^39 below the largest of its tile is not carried, and a
  *                   non-finite sample makes its whole tile non-finite;
- *   306 .. 8192     overlap-save (the frequency-domain convolution doc/notes:81-82 names) when
- *                   flags == 0, nxx == nx and the rows hold at least two transforms; any other
+ *   306 .. 16384    overlap-save (the frequency-domain convolution doc/notes:81-82 names) when
+ *                   flags == 0, nxx == nx and the rows hold enough work (up to 899 taps: two
+ *                   transforms of four times the tap count; from 900 taps: nx * nh >= 4e5, in
+ *                   blocks of 16384 samples, of 32768 from rows of 65536 samples); any other
  *                   call, and longer filters, run the f32 kernel.
  * DSPMI_FIR_VARIANT = mfma | f16 | bf16 | ols in the environment at creation pins the f32 kernel,
  * the f16 kernel, its three-part bf16 sibling (no scale, full f32 exponent range) or overlap-save. */

@@ -127,13 +127,13 @@ def test_fir_plan_takes_the_long_block_path_with_history(nh):
 
 @pytest.mark.parametrize("nh", [900, 1024, 2048])
 def test_fir_plan_of_a_thousand_taps_by_row_length(nh):
-    """From 900 to 2048 taps an f32 FIR plan holds two overlap-save plans: rows of 65536 samples
-    and more go through 32768-sample blocks, shorter rows through the shorter transform; both
-    with carried history against the oracle."""
+    """From 900 taps an f32 FIR plan holds two overlap-save plans: rows of 65536 samples and more
+    go through 32768-sample blocks, shorter rows through 16384-sample blocks; both with carried
+    history against the oracle."""
     rng = np.random.default_rng(nh)
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     plan = dsp_amd.FirPlan(h, "f32")
-    assert plan.variant.startswith("fir_f32_overlap_save_n") and plan.variant.endswith("_or_n32768")
+    assert plan.variant == "fir_f32_overlap_save_n32768"
     for nchan, chunk in ((2, 70001), (3, 30000)):
         x = rng.uniform(-1, 1, (nchan, 2 * chunk)).astype(np.float32)
         xd = torch.from_numpy(x).cuda()
@@ -143,6 +143,34 @@ def test_fir_plan_of_a_thousand_taps_by_row_length(nh):
         want = oracle.fir_batch_f32(x, h, 2 * chunk)
         for c in range(nchan):
             check_blocks(got[c], want[c], x[c], h, (nh, chunk, c))
+
+
+@pytest.mark.parametrize("nh,nchan,nx", [(900, 5, 300), (900, 5, 3000), (1536, 4, 20000), (2049, 5, 1000), (2049, 3, 40000),
+                                         (8191, 5, 300), (8191, 5, 4096), (8191, 3, 40000), (8192, 2, 16385),
+                                         (12000, 2, 20000), (16384, 2, 3000)])
+def test_long_filters_on_short_rows(nh, nchan, nx):
+    """Rows shorter than two 32768-sample blocks: from 900 taps an f32 FIR plan filters them through
+    16384-sample blocks (one real block per 8192-point transform; 32768-sample blocks beyond 8192
+    taps) once a row holds enough work, and through the direct kernel below that; either way the
+    oracle's outputs, with carried history."""
+    rng = np.random.default_rng(nh + nx)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert "overlap_save" in plan.variant
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    got = plan.exec(torch.from_numpy(x).cuda(), hist=torch.from_numpy(hist).cuda()).cpu().numpy()
+    full = np.concatenate([hist, x], axis=1)
+    want = oracle.fir_batch_f32(full, h, full.shape[1])[:, nh - 1:]
+    for c in range(nchan):
+        for lo in range(0, nx, BLK):
+            w = want[c, lo:lo + BLK]
+            assert np.linalg.norm(got[c, lo:lo + BLK] - w) <= TOL_FIR * np.linalg.norm(w), (nh, nx, c, lo)
+    # and from zero state (start-up blocks are held to the absolute bound, see check_blocks)
+    got0 = plan.exec(torch.from_numpy(x).cuda()).cpu().numpy()
+    want0 = oracle.fir_batch_f32(x, h, nx)
+    for c in range(nchan):
+        check_blocks(got0[c], want0[c], x[c], h, (nh, nx, c))
 
 
 @pytest.mark.parametrize("nh,fft_n", [(127, 1024), (1000, 4096), (8191, 16384), (8191, 32768)])
