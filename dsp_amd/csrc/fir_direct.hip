@@ -786,6 +786,8 @@ struct dspmi_fir_plan {
     dspmi_ols_t ols = nullptr;
     unsigned ols_n = 0;
     dspmi_ols_t ols_16k = nullptr;   // 16384-sample blocks, one per transform: long filters on rows shorter than that
+    dspmi_ols_t ols_small = nullptr; // the shortest transform that holds the taps twice: rows of a few blocks
+    unsigned ols_small_n = 0;
     // f32 plans of up to 32 * kSplitMaxSlices - 15 taps: the tap matrix of the bf16 kernel, as
     // [slice][part][lane] register images, and its slice count
     void *split_tab = nullptr;
@@ -1273,6 +1275,16 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
                 if (pl->ols && n == 32768 && nh <= 8192 && real_blocks &&
                     dspmi_ols_create_f32(&pl->ols_16k, taps, nh, 16384, device) != DSPMI_OK)
                     pl->ols_16k = nullptr;
+                // Rows of a few blocks: what counts is how many transforms a row costs, not how
+                // much of each block is overlap, and the direct kernel's 4096-output tiles are
+                // mostly empty (2^26 samples as rows of 1024, 511 taps: 2.03 ms direct, 0.32 ms with
+                // 1024-point transforms).  Plans below 900 taps also hold the shortest transform
+                // that fits, and a call takes whichever costs less for its row length.
+                unsigned ns = 1024;
+                while (ns < 2 * nh) ns <<= 1;
+                if (pl->ols && n < 32768 && ns < n && dspmi_ols_create_f32(&pl->ols_small, taps, nh, ns, device) == DSPMI_OK)
+                    pl->ols_small_n = ns;
+                else pl->ols_small = nullptr;
             }
         }
     }
@@ -1309,11 +1321,30 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
         if (pl->ols && flags == 0 && nxx == nx) {
             const unsigned long long work = (unsigned long long)nx * pl->nh;
-            if (nx >= 2 * pl->ols_n) return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
-            if (pl->ols_16k && work >= 400000ull)
-                return dspmi_ols_exec_f32(pl->ols_16k, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
-            if (!pl->ols_16k && pl->nh > 8192 && work >= 4000000ull)  // beyond 8192 taps only the 32768-sample blocks fit
+            if (nx >= 2 * pl->ols_n && !(pl->ols_small && nx < 8 * pl->ols_n))
                 return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+            // Below that only rows that are mostly steady state: a transform's rounding error is
+            // relative to the whole block that goes through it, so the first nh-1 outputs of a row
+            // that starts from zero state -- sums over the filter's small outer taps -- come out
+            // with a larger error relative to themselves; a row that is little else keeps the
+            // direct kernel.
+            const bool settled = hist != nullptr || nx >= 2 * pl->nh;
+            if (!settled) {
+                // (falls through to the direct kernels below)
+            } else if (pl->ols_n < 32768) {
+                // transforms per row (two blocks ride one) times the transform's size, for the plan's
+                // own length and the shortest one
+                auto cost = [&](unsigned n) {
+                    const unsigned long long blocks = ((unsigned long long)nx + (n - pl->nh)) / (n - pl->nh + 1);
+                    return ((blocks + 1) / 2) * n;
+                };
+                dspmi_ols_t pick = pl->ols_small && cost(pl->ols_small_n) <= cost(pl->ols_n) ? pl->ols_small : pl->ols;
+                return dspmi_ols_exec_f32(pick, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+            } else if (pl->ols_16k && work >= 400000ull) {
+                return dspmi_ols_exec_f32(pl->ols_16k, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+            } else if (!pl->ols_16k && pl->nh > 8192 && work >= 4000000ull) {  // beyond 8192 taps only the 32768-sample blocks fit
+                return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
+            }
         }
         if (pl->half_tab && pl->half_exec && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
@@ -1379,6 +1410,7 @@ int dspmi_fir_destroy(dspmi_fir_t plan)
     if (!plan) return DSPMI_OK;
     if (plan->ols) (void)dspmi_ols_destroy(plan->ols);
     if (plan->ols_16k) (void)dspmi_ols_destroy(plan->ols_16k);
+    if (plan->ols_small) (void)dspmi_ols_destroy(plan->ols_small);
     (void)hipFree(plan->split_tab);
     (void)hipFree(plan->half_tab);
     hipError_t e = hipFree(plan->taps_dev);

@@ -173,6 +173,32 @@ def test_long_filters_on_short_rows(nh, nchan, nx):
         check_blocks(got0[c], want0[c], x[c], h, (nh, nx, c))
 
 
+@pytest.mark.parametrize("nh", [306, 511, 800])
+@pytest.mark.parametrize("nchan,nx", [(9, 100), (7, 256), (5, 1500), (4, 4096), (3, 9000), (2, 40000)])
+def test_mid_length_filters_by_row_length(nh, nchan, nx):
+    """306 .. 899 taps: an f32 FIR plan holds the transform of four times the tap count and the
+    shortest one that fits, and a call runs whichever costs fewer transforms for its row length
+    (rows of a few hundred samples included, which the direct kernel's 4096-output tiles serve
+    badly); the oracle's outputs either way, with carried history and from zero state."""
+    rng = np.random.default_rng(nh + nx)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert "overlap_save" in plan.variant
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    got = plan.exec(torch.from_numpy(x).cuda(), hist=torch.from_numpy(hist).cuda()).cpu().numpy()
+    full = np.concatenate([hist, x], axis=1)
+    want = oracle.fir_batch_f32(full, h, full.shape[1])[:, nh - 1:]
+    for c in range(nchan):
+        for lo in range(0, nx, BLK):
+            w = want[c, lo:lo + BLK]
+            assert np.linalg.norm(got[c, lo:lo + BLK] - w) <= TOL_FIR * np.linalg.norm(w), (nh, nx, c, lo)
+    got0 = plan.exec(torch.from_numpy(x).cuda()).cpu().numpy()
+    want0 = oracle.fir_batch_f32(x, h, nx)
+    for c in range(nchan):
+        check_blocks(got0[c], want0[c], x[c], h, (nh, nx, c))
+
+
 @pytest.mark.parametrize("nh,fft_n", [(127, 1024), (1000, 4096), (8191, 16384), (8191, 32768)])
 def test_fused_kernels_agree_with_the_five_kernel_composition(nh, fft_n, monkeypatch):
     """DSPMI_OLS_COMPOSED=1 runs the same arithmetic as five kernels through HBM (gather, batched

@@ -1,5 +1,5 @@
-"""Long filters on rows of a few thousand samples: overlap-save with one or two long blocks per row
-against the direct matrix kernel, and what an f32 FIR plan picks by itself.  512 channels; ms per launch."""
+"""Mid-length filters (306 .. 899 taps) on many short rows: the fused overlap-save kernels by transform
+length against the direct matrix kernel.  2^26 samples as rows of 256 ... 8192; ms per launch."""
 import os
 import sys
 
@@ -11,9 +11,9 @@ import dsp_amd  # noqa: E402
 import oracle   # noqa: E402
 
 
-def timed(fn, n=6):
+def timed(fn, n=8):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(3):
+    for _ in range(4):
         fn()
     torch.cuda.synchronize()
     ev0.record()
@@ -25,23 +25,24 @@ def timed(fn, n=6):
 
 
 def main():
-    nchan = 512
-    for nh in (900, 2049, 4096, 8191):
+    total = 1 << 26
+    for nh in (306, 511, 800):
         h = oracle.windowed_sinc_taps(nh).astype(np.float32)
         os.environ["DSPMI_FIR_VARIANT"] = "mfma"
         direct = dsp_amd.FirPlan(h, "f32")
         del os.environ["DSPMI_FIR_VARIANT"]
-        plans = {n: dsp_amd.OlsPlan(h, n) for n in (16384, 32768) if n >= 2 * nh}
         auto = dsp_amd.FirPlan(h, "f32")
-        for nx in (512, 1024, 2048, 4096, 8192, 16384, 32768, 49152):
+        plans = {n: dsp_amd.OlsPlan(h, n) for n in (1024, 2048, 4096, 16384) if n >= 2 * nh}
+        for nx in (256, 512, 1024, 2048, 4096, 8192):
+            nchan = total // nx
             x = torch.rand((nchan, nx), device="cuda") * 2 - 1
             y = torch.empty_like(x)
             hist = torch.rand((nchan, nh - 1), device="cuda") * 2 - 1   # carried history: every output is steady state
-            row = ["direct %8.3f" % timed(lambda: direct.exec(x, nx, y=y, hist=hist))]
+            row = ["direct %7.3f" % timed(lambda: direct.exec(x, nx, y=y, hist=hist))]
             for n, pl in plans.items():
-                row.append("ols%d %8.3f" % (n, timed(lambda: pl.exec(x, y=y, hist=hist))))
-            row.append("plan %8.3f" % timed(lambda: auto.exec(x, nx, y=y, hist=hist)))
-            print("nh %5d nx %6d (nx*nh %.1e): %s" % (nh, nx, nx * nh, "   ".join(row)), flush=True)
+                row.append("ols%d %7.3f" % (n, timed(lambda: pl.exec(x, y=y, hist=hist))))
+            row.append("plan(%s) %7.3f" % (auto.variant.rsplit("_", 1)[1], timed(lambda: auto.exec(x, nx, y=y, hist=hist))))
+            print("nh %4d rows of %5d: %s" % (nh, nx, "  ".join(row)), flush=True)
 
 
 if __name__ == "__main__":
