@@ -864,31 +864,32 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
 // A filter this short is a copy with a few multiply-adds on the way.  The tile kernels above
 // load a tile, then store a tile; the fastest copy on this chip is the simplest one -- one
 // 16-byte element per thread, a grid that covers the array.  Here a thread takes four consecutive
-// outputs: it loads its own four samples and the sixteen before them as five aligned 16-byte
-// loads (four of the five are what lower-numbered lanes of the same wave load as well: cache
-// hits), sums sixteen products per output with the taps in scalar registers, and stores 16 bytes.
-// The first four threads of a row (history or zeros before the row) and the last one of a row
+// outputs: it loads its own four samples and the NT before them (NT = the tap count rounded up
+// to a multiple of four) as NT/4 + 1 aligned 16-byte loads (all but one are what lower-numbered
+// lanes of the same wave load as well: cache hits), sums NT products per output with the taps in
+// scalar registers, and stores 16 bytes.  The first NT/4 threads of a row (history or zeros before the row) and the last one of a row
 // whose length is not a multiple of four go element by element.
 // Requires nxx == nx, no flags, rows that start on 16-byte boundaries.  512 x 2^20 samples, 16 taps:
 // 0.732 ms against 0.752 for the tile kernel on the same box (5.88 against 5.72 TB/s); eight or
 // sixteen outputs per thread are slower (0.806, 1.50 ms: a lane's accesses are then 32 or 64 bytes apart).
-__global__ __launch_bounds__(256) void fir_stream16_kernel(const FirParams<float> p, unsigned rows_per_y)
+template <int NT>  // taps, rounded up to a multiple of four
+__global__ __launch_bounds__(256) void fir_stream_kernel(const FirParams<float> p, unsigned rows_per_y)
 {
     const size_t row = (size_t)blockIdx.y + (size_t)rows_per_y * blockIdx.z;
     const unsigned q = blockIdx.x * 256u + threadIdx.x;  // which four outputs of the row
     const size_t i0 = (size_t)q * 4;
     if (i0 >= p.nx) return;
-    float h[16];
+    float h[NT];
 #pragma unroll
-    for (int j = 0; j < 16; j++) h[j] = p.taps[j];  // uniform: scalar loads (zero-padded past nh)
+    for (int j = 0; j < NT; j++) h[j] = p.taps[j];  // uniform: scalar loads (zero-padded past nh)
     const float *x = p.x + row * p.x_stride;
     float *y = p.y + row * p.y_stride;
-    float w[20];
-    const bool whole = q >= 4 && i0 + 4 <= p.nx;
+    float w[NT + 4];
+    const bool whole = i0 >= NT && i0 + 4 <= p.nx;
     if (whole) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + i0 - 16);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + i0 - NT);
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < NT / 4 + 1; k++) {
             const f32x4 v = src[k];
             w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
         }
@@ -896,8 +897,8 @@ __global__ __launch_bounds__(256) void fir_stream16_kernel(const FirParams<float
         const float *hist = p.hist ? p.hist + row * p.hist_stride : nullptr;
         const long nh = p.nh;
 #pragma unroll
-        for (int k = 0; k < 20; k++) {
-            const long s = (long)i0 - 16 + k;
+        for (int k = 0; k < NT + 4; k++) {
+            const long s = (long)i0 - NT + k;
             w[k] = s >= 0 ? (s < (long)p.nx ? x[s] : 0.f) : (hist && s >= 1 - nh ? hist[nh - 1 + s] : 0.f);
         }
     }
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(256) void fir_stream16_kernel(const FirParams<float
     for (int o = 0; o < 4; o++) {
         float a = 0.f;
 #pragma unroll
-        for (int j = 15; j >= 0; j--) a = __builtin_fmaf(h[j], w[16 + o - j], a);  // descending tap index, as the tile kernel sums
+        for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(h[j], w[NT + o - j], a);  // descending tap index, as the tile kernel sums
         acc[o] = a;
     }
     if (whole) {
@@ -919,23 +920,29 @@ __global__ __launch_bounds__(256) void fir_stream16_kernel(const FirParams<float
     }
 }
 
+// Beyond 16 taps the multiply-adds of four outputs per lane cost more than the stream (512 x 2^20
+// samples: 20 taps 0.805 ms against 0.735 for the tile kernel, 32 taps 1.06 against 0.735); below,
+// the stream kernel is ahead, the more the fewer taps (8 taps: 0.674 against 0.771 ms = 6.4 TB/s).
+constexpr unsigned kStreamMaxTaps = 16;
+
 // nullptr-safe test of what the stream kernel needs; the caller falls back to the tile kernel otherwise
-bool stream16_applies(const FirParams<float> &p)
+bool stream_applies(const FirParams<float> &p)
 {
     const char *env = getenv("DSPMI_FIR_STREAM");  // 0: keep the tile kernel (A/B)
     if (env && !atoi(env)) return false;
-    return p.nh <= 16 && p.nhp >= 16 && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & 3) && !(p.y_stride & 3) &&
-           !((reinterpret_cast<size_t>(p.x) | reinterpret_cast<size_t>(p.y)) & 15);
+    return p.nh <= kStreamMaxTaps && p.nhp >= ((p.nh + 3) & ~3u) && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & 3) &&
+           !(p.y_stride & 3) && !((reinterpret_cast<size_t>(p.x) | reinterpret_cast<size_t>(p.y)) & 15);
 }
 
-int launch_stream16(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
+template <int NT>
+int launch_stream_t(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 {
     const unsigned quads = (unsigned)(((unsigned long long)p.nx + 3) / 4);
     const unsigned gx = (quads + 255) / 256;
     const unsigned gy = nchan < 65535u ? nchan : 65535u;
     // rows beyond 65535 go into the grid's third dimension; the remainder is a second launch
     const unsigned gz = nchan / gy;
-    hipLaunchKernelGGL(fir_stream16_kernel, dim3(gx, gy, gz), dim3(256), 0, stream, p, gy);
+    hipLaunchKernelGGL(fir_stream_kernel<NT>, dim3(gx, gy, gz), dim3(256), 0, stream, p, gy);
     DSPMI_HIP(hipGetLastError());
     const unsigned done = gy * gz;
     if (done < nchan) {
@@ -943,10 +950,21 @@ int launch_stream16(const FirParams<float> &p, unsigned nchan, hipStream_t strea
         r.x += (size_t)done * p.x_stride;
         r.y += (size_t)done * p.y_stride;
         if (r.hist) r.hist += (size_t)done * p.hist_stride;
-        hipLaunchKernelGGL(fir_stream16_kernel, dim3(gx, nchan - done, 1), dim3(256), 0, stream, r, nchan - done);
+        hipLaunchKernelGGL(fir_stream_kernel<NT>, dim3(gx, nchan - done, 1), dim3(256), 0, stream, r, nchan - done);
         DSPMI_HIP(hipGetLastError());
     }
     return DSPMI_OK;
+}
+
+int launch_stream(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
+{
+    static_assert(kStreamMaxTaps == 16, "one instance per multiple of four taps");
+    switch ((p.nh + 3) / 4) {
+    case 0: case 1: return launch_stream_t<4>(p, nchan, stream);
+    case 2: return launch_stream_t<8>(p, nchan, stream);
+    case 3: return launch_stream_t<12>(p, nchan, stream);
+    default: return launch_stream_t<16>(p, nchan, stream);
+    }
 }
 
 int launch_mfma(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
@@ -1291,8 +1309,8 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
     if (pl->half_tab && pl->half_exec) snprintf(pl->name, sizeof pl->name, "fir_f32_f16x2_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->split_tab) snprintf(pl->name, sizeof pl->name, "fir_f32_bf16x3_mfma16x16x32_s%d", pl->split_ns);
     else if (pl->ols) snprintf(pl->name, sizeof pl->name, "fir_f32_overlap_save_n%u", pl->ols_n);
-    else if (precision == DSPMI_F32 && pl->variant == V_F32_MFMA && !pl->pinned && nh <= 16)
-        snprintf(pl->name, sizeof pl->name, "fir_f32_stream16");  // (calls it does not cover run the matrix kernel)
+    else if (precision == DSPMI_F32 && pl->variant == V_F32_MFMA && !pl->pinned && nh <= kStreamMaxTaps)
+        snprintf(pl->name, sizeof pl->name, "fir_f32_stream%u", (nh + 3) & ~3u);  // (calls it does not cover run the matrix kernel)
     else snprintf(pl->name, sizeof pl->name, "%s", kVariantName[pl->variant]);
     *out = pl;
     return DSPMI_OK;
@@ -1349,7 +1367,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         if (pl->half_tab && pl->half_exec && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
-            if (!pl->pinned && stream16_applies(p)) return launch_stream16(p, nchan, s);
+            if (!pl->pinned && stream_applies(p)) return launch_stream(p, nchan, s);
             return launch_mfma(p, nchan, s);
         }
         if (pl->variant == V_F32_SHORT) {
