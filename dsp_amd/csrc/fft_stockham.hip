@@ -444,19 +444,24 @@ constexpr double table_iters(size_t tw_entries, size_t esz)
 // one twiddle table per workgroup): eight 1024-point frames per workgroup share the table, which
 // fits 16 waves on a CU where four-frame workgroups fit 12.
 template <int N, int NT> constexpr int ols_block_threads() { return N == 1024 ? 512 : block_threads<NT>(); }
+// The complex kernel at 1024 points (f32): eight frames per workgroup share one 8 KB twiddle table,
+// so two workgroups = sixteen waves fit a CU where three four-frame workgroups are twelve; with one
+// frame-block per workgroup 2.89 ms for 2^20 frames against 2.98 (5.94 against 5.77 TB/s; sixteen
+// frames per workgroup, one workgroup per CU: 3.6-3.7 ms).
+template <typename T, int N, int NT> constexpr int c2c_block_threads() { return (N == 1024 && sizeof(T) == 4) ? 512 : block_threads<NT>(); }
 
 // flag bits of the c2c kernel
 constexpr int kFftBackward = 1;   // conj . forward . conj
 // bits 1-2: log2 of the number of fronts the frame-blocks are visited from (see the frame loop)
 
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
-__global__ __launch_bounds__(block_threads<NT>()) void fft_c2c_kernel(const C<T> *in, C<T> *out,
+__global__ __launch_bounds__((c2c_block_threads<T, N, NT>())) void fft_c2c_kernel(const C<T> *in, C<T> *out,
                                                                       const C<T> *__restrict__ tw, size_t batch,
                                                                       int flags)
 {
     static_assert(R0 * R1 * R2 * R3 == N, "radices must multiply to N");
     constexpr int P = N / NT;
-    constexpr int BT = block_threads<NT>();
+    constexpr int BT = c2c_block_threads<T, N, NT>();
     constexpr int FPB = BT / NT;  // frames per workgroup per iteration
     constexpr int NS1 = R0, NS2 = R0 * R1, NS3 = R0 * R1 * R2;
     constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
@@ -2322,7 +2327,7 @@ int launch_c2c_rows(const void *in, void *out, const void *tw, size_t batch, int
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
 {
-    constexpr int BT = block_threads<NT>();
+    constexpr int BT = c2c_block_threads<T, N, NT>();
     constexpr int FPB = BT / NT;
     constexpr bool single_pass = R1 == 1 && R2 == 1 && R3 == 1;  // global -> registers -> global
     constexpr size_t tw_entries = lds_twiddle_entries(TW, R0, R1, R2, R3, N);
@@ -2358,6 +2363,7 @@ int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int back
     // short frames staged through LDS and the prefetching variant keep a persistent grid; the rest
     // launch one workgroup per few frame-blocks (see grid_for)
     double iters = (staged || PREFETCH || !lds) ? 0.0 : table_iters(tw_entries, sizeof(C<T>));
+    if (iters > 0 && BT > block_threads<NT>()) iters = 1.0;  // eight frames per table already (2.89 ms against 2.93 with two frame-blocks, 3.20 with four)
     {
         const char *env = getenv("DSPMI_FFT_ITERS");  // experiment: frame-blocks per workgroup
         if (env && atof(env) > 0) iters = atof(env);
