@@ -2467,7 +2467,7 @@ const FftEntry kF32[] = {
     F32S(2, 1, 2, 1, 1, 1),         F32S(4, 1, 4, 1, 1, 1),         F32S(8, 1, 8, 1, 1, 1),
     F32S(16, 1, 16, 1, 1, 1),       F32S(32, 2, 16, 2, 1, 1),       F32S(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
-    F32(1024, 64, 16, 16, 4, 1),    F32(2048, 128, 16, 16, 8, 1),    F32T(4096, 256, 16, 16, 16, 1, 2),
+    F32(1024, 64, 16, 16, 4, 1),    F32T(2048, 128, 16, 16, 8, 1, 2), F32T(4096, 256, 16, 16, 16, 1, 2),
     F32T(8192, 512, 16, 16, 16, 2, 3),
     {16384, launch_c2c_rows<0>, launch_c2c_rows<3>, "fft_f32_n16384_r16_rows1024", nullptr, nullptr},
     {32768, launch_c2c_rows32<0>, launch_c2c_rows32<3>, "fft_f32_n32768_r32_rows1024", nullptr, nullptr},
