@@ -878,31 +878,21 @@ __global__ __launch_bounds__(256) void fir_stream_kernel(const FirParams<float> 
     const size_t row = (size_t)blockIdx.y + (size_t)rows_per_y * blockIdx.z;
     const unsigned q = blockIdx.x * 256u + threadIdx.x;  // which four outputs of the row
     const size_t i0 = (size_t)q * 4;
-    if (i0 >= p.nx) return;
+    // the ends of a row belong to fir_stream_edge_kernel: kept in here, the one wave per row that
+    // meets them runs a chain of dependent loads and its workgroup outlives twenty others (rows
+    // of 16384 samples: 593 Gsamples/s against 730 on rows of 2^20)
+    if (i0 < NT || i0 + 4 > p.nx) return;
     float h[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) h[j] = p.taps[j];  // uniform: scalar loads (zero-padded past nh)
-    const float *x = p.x + row * p.x_stride;
-    float *y = p.y + row * p.y_stride;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.x + row * p.x_stride + i0 - NT);
     float w[NT + 4];
-    const bool whole = i0 >= NT && i0 + 4 <= p.nx;
-    if (whole) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + i0 - NT);
 #pragma unroll
-        for (int k = 0; k < NT / 4 + 1; k++) {
-            const f32x4 v = src[k];
-            w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
-        }
-    } else {
-        const float *hist = p.hist ? p.hist + row * p.hist_stride : nullptr;
-        const long nh = p.nh;
-#pragma unroll
-        for (int k = 0; k < NT + 4; k++) {
-            const long s = (long)i0 - NT + k;
-            w[k] = s >= 0 ? (s < (long)p.nx ? x[s] : 0.f) : (hist && s >= 1 - nh ? hist[nh - 1 + s] : 0.f);
-        }
+    for (int k = 0; k < NT / 4 + 1; k++) {
+        const f32x4 v = src[k];
+        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
     }
-    float acc[4];
+    f32x4 acc;
 #pragma unroll
     for (int o = 0; o < 4; o++) {
         float a = 0.f;
@@ -910,13 +900,46 @@ __global__ __launch_bounds__(256) void fir_stream_kernel(const FirParams<float> 
         for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(h[j], w[NT + o - j], a);  // descending tap index, as the tile kernel sums
         acc[o] = a;
     }
-    if (whole) {
-        const f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(y + i0));
-    } else {
+    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(p.y + row * p.y_stride + i0));
+}
+
+// The groups of four outputs the kernel above leaves out: the first NT/4 of every row (history or
+// zeros before the row) and the last one of a row whose length is not a multiple of four.  One
+// lane each, element by element, every load unconditional from a clamped index.
+template <int NT>
+__global__ __launch_bounds__(64) void fir_stream_edge_kernel(const FirParams<float> p, unsigned nchan)
+{
+    constexpr unsigned PER_ROW = NT / 4 + 1;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t row = t / PER_ROW;
+    const unsigned e = (unsigned)(t - row * PER_ROW);
+    if (row >= nchan) return;
+    const long nx = p.nx, nh = p.nh;
+    const long qlast = (nx - 1) / 4;
+    long q = e;
+    if (e == NT / 4) {
+        if (!(nx & 3) || qlast < NT / 4) return;  // the row ends on a whole group, or its last group is one of the first
+        q = qlast;
+    }
+    const long i0 = 4 * q;
+    if (i0 >= nx) return;
+    const float *x = p.x + row * p.x_stride;
+    const float *hist = (p.hist && nh > 1) ? p.hist + row * p.hist_stride : nullptr;
+    float w[NT + 4];
 #pragma unroll
-        for (int o = 0; o < 4; o++)
-            if (i0 + o < p.nx) y[i0 + o] = acc[o];
+    for (int k = 0; k < NT + 4; k++) {
+        const long s = i0 - NT + k, u = nh - 1 + s;  // position in the row, in the history
+        const float vx = x[s < 0 ? 0 : (s >= nx ? nx - 1 : s)];
+        const float vh = hist ? hist[u < 0 ? 0 : (u > nh - 2 ? nh - 2 : u)] : 0.f;
+        w[k] = s >= 0 ? (s < nx ? vx : 0.f) : (s >= 1 - nh ? vh : 0.f);
+    }
+    float *y = p.y + row * p.y_stride;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(p.taps[j], w[NT + o - j], a);
+        if (i0 + o < nx) y[i0 + o] = a;
     }
 }
 
@@ -924,13 +947,18 @@ __global__ __launch_bounds__(256) void fir_stream_kernel(const FirParams<float> 
 // samples: 20 taps 0.805 ms against 0.735 for the tile kernel, 32 taps 1.06 against 0.735); below,
 // the stream kernel is ahead, the more the fewer taps (8 taps: 0.674 against 0.771 ms = 6.4 TB/s).
 constexpr unsigned kStreamMaxTaps = 16;
+// ... except on rows shorter than the tile kernel's 4096-output tiles, which that kernel serves
+// badly: there the stream kernel takes filters of up to 32 taps (2^27 samples as rows of 1024, 21
+// taps: 246 -> 488 Gsamples/s; rows of 2048 are level from 25 taps on).
+constexpr unsigned kStreamMaxTapsShortRows = 32;
 
 // nullptr-safe test of what the stream kernel needs; the caller falls back to the tile kernel otherwise
 bool stream_applies(const FirParams<float> &p)
 {
     const char *env = getenv("DSPMI_FIR_STREAM");  // 0: keep the tile kernel (A/B)
     if (env && !atoi(env)) return false;
-    return p.nh <= kStreamMaxTaps && p.nhp >= ((p.nh + 3) & ~3u) && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & 3) &&
+    const bool taps_ok = p.nh <= kStreamMaxTaps || (p.nh <= kStreamMaxTapsShortRows && p.nx < (p.nh <= 24 ? 4096u : 2048u));
+    return taps_ok && p.nhp >= ((p.nh + 3) & ~3u) && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & 3) &&
            !(p.y_stride & 3) && !((reinterpret_cast<size_t>(p.x) | reinterpret_cast<size_t>(p.y)) & 15);
 }
 
@@ -953,17 +981,24 @@ int launch_stream_t(const FirParams<float> &p, unsigned nchan, hipStream_t strea
         hipLaunchKernelGGL(fir_stream_kernel<NT>, dim3(gx, nchan - done, 1), dim3(256), 0, stream, r, nchan - done);
         DSPMI_HIP(hipGetLastError());
     }
+    const unsigned long long edges = (unsigned long long)nchan * (NT / 4 + 1);
+    hipLaunchKernelGGL(fir_stream_edge_kernel<NT>, dim3((unsigned)((edges + 63) / 64)), dim3(64), 0, stream, p, nchan);
+    DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
 
 int launch_stream(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
 {
-    static_assert(kStreamMaxTaps == 16, "one instance per multiple of four taps");
+    static_assert(kStreamMaxTapsShortRows == 32, "one instance per multiple of four taps");
     switch ((p.nh + 3) / 4) {
     case 0: case 1: return launch_stream_t<4>(p, nchan, stream);
     case 2: return launch_stream_t<8>(p, nchan, stream);
     case 3: return launch_stream_t<12>(p, nchan, stream);
-    default: return launch_stream_t<16>(p, nchan, stream);
+    case 4: return launch_stream_t<16>(p, nchan, stream);
+    case 5: return launch_stream_t<20>(p, nchan, stream);
+    case 6: return launch_stream_t<24>(p, nchan, stream);
+    case 7: return launch_stream_t<28>(p, nchan, stream);
+    default: return launch_stream_t<32>(p, nchan, stream);
     }
 }
 

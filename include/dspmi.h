@@ -74,7 +74,7 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  * 4096 outputs) of the double sum:
  *   up to 16 taps   f32 multiply-accumulate chains straight from global memory, four outputs per
  *                   lane (flags == 0, nxx == nx, rows on 16-byte boundaries; the next line's
- *                   kernel otherwise);
+ *                   kernel otherwise; also up to 32 taps on rows of fewer than 2048 samples);
  *   up to 32 taps   f32 multiply-accumulate chains on the matrix unit;
  *   33 .. 305       the same sum through the f16 matrix pipe: samples and taps as two f16 parts
  *                   each, under one power-of-two scale per 4096-output tile, accumulated in f32.

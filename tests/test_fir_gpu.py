@@ -481,13 +481,14 @@ def test_split_kernels_degenerate_shapes(monkeypatch, split_kind):
         assert_blocks(got[c], want[c], h, np.concatenate([hist[c], x[c]]), c)
 
 
-@pytest.mark.parametrize("nh", [1, 4, 5, 9, 12, 13, 16])
-@pytest.mark.parametrize("nx,nchan,stride_pad", [(64, 1, 0), (65, 3, 3), (4099, 3, 1), (100000, 2, 0), (100002, 2, 2)])
+@pytest.mark.parametrize("nh", [1, 4, 5, 9, 12, 13, 16, 17, 21, 32])
+@pytest.mark.parametrize("nx,nchan,stride_pad", [(64, 1, 0), (65, 3, 3), (1023, 5, 1), (2047, 2, 1), (4099, 3, 1), (100000, 2, 0), (100002, 2, 2)])
 @pytest.mark.parametrize("with_hist", [False, True])
 def test_short_filters_as_a_stream(nh, nx, nchan, stride_pad, with_hist, monkeypatch):
-    """Up to 16 taps an f32 plan runs calls with as many outputs as inputs on 16-byte aligned rows
-    through a kernel without tiles (four outputs per thread straight from global memory); other
-    calls, and DSPMI_FIR_STREAM=0, run the matrix kernel.  Both against the oracle per row, and
+    """Up to 16 taps (up to 32 on rows shorter than the matrix kernel's tiles) an f32 plan runs calls
+    with as many outputs as inputs on 16-byte aligned rows through a kernel without tiles (four
+    outputs per thread straight from global memory, the ends of every row by a second small kernel);
+    other calls, and DSPMI_FIR_STREAM=0, run the matrix kernel.  Both against the oracle per row, and
     against each other: row lengths that are not multiples of four, padded strides, history."""
     rng = np.random.default_rng(nh * 1000 + nx)
     h = (oracle.windowed_sinc_taps(nh) if nh > 1 else np.array([0.75])).astype(np.float32)
@@ -501,7 +502,7 @@ def test_short_filters_as_a_stream(nh, nx, nchan, stride_pad, with_hist, monkeyp
     hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32) if with_hist and nh > 1 else None
     hd = None if hist is None else torch.from_numpy(hist).cuda()
     plan = dsp_amd.FirPlan(h, "f32")
-    assert plan.variant.startswith("fir_f32_stream")
+    assert plan.variant.startswith("fir_f32_stream") == (nh <= 16)
     ybuf = torch.zeros((nchan, stride), dtype=torch.float32, device="cuda")
     a = plan.exec(xd, nx, y=ybuf[:, :nx], hist=hd).cpu().numpy().copy()
     monkeypatch.setenv("DSPMI_FIR_STREAM", "0")

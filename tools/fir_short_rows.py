@@ -13,7 +13,7 @@ import oracle   # noqa: E402
 def main():
     total = 1 << 27
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for nh in (16, 21, 127, 305, 511):
+    for nh in (16, 21, 32, 127, 305, 511):
         h = (np.asarray(oracle.TAPS16) if nh == 16 else oracle.windowed_sinc_taps(nh)).astype(np.float32)
         plan = dsp_amd.FirPlan(h, "f32")
         row = []
@@ -21,7 +21,7 @@ def main():
             nchan = total // nx
             x = torch.rand((nchan, nx), device="cuda") * 2 - 1
             y = torch.empty_like(x)
-            for _ in range(3):
+            for _ in range(40):
                 plan.exec(x, nx, y=y)
             torch.cuda.synchronize()
             ev0.record()
