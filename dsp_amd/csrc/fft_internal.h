@@ -52,8 +52,8 @@ typedef int (*ols_launch_fn)(const OlsLaunch &o, const void *tw, int num_cu, hip
 ols_launch_fn ols_find(unsigned n);
 // The same with one real block of `block` samples per block/2-point complex transform (32768 or
 // 16384: 512-lane workgroups, two or three per CU), the transform as R = block/1024 rows of 512
-// points.  H = two tables of block/2 complex entries, Hev / (block/2) and (i/2) Hod / (block/2)
-// (the transforms of the even and odd taps), each stored row by row: entry k1 + R k2 at [k1][k2];
+// points.  H = block/2 entries of two complex values, {Hev / (block/2), (i/2) Hod / (block/2)}
+// (the transforms of the even and odd taps), stored row by row: entry k1 + R k2 at [k1][k2];
 // tw = exp(-2 pi i k / 512), k < 512, then exp(-2 pi i k1 n2 / (block/2)) as [R][512], then
 // exp(-2 pi i (k1 + R l) / (block/2)) as [R][64].
 ols_launch_fn ols_find_real(unsigned block);

@@ -1656,10 +1656,11 @@ int launch_ols_wave(const dspmi::OlsLaunch &o, const void *tables, int num_cu, h
 // is in lane 63-l, register 7-r of the other row, one cross-lane read away.  A lane of a pair of
 // rows works out both bins and hands the partner's result back the same way; the two rows that
 // pair with themselves work out every bin from its own side.
-// Tables (H): [0] Hev / N2, [1] (i/2) Hod / N2, both row by row ([k1][k2]).  (tw): exp(-2 pi i k / 512),
+// Tables (H): one 16-byte entry per bin, {Hev / N2, (i/2) Hod / N2}, row by row ([k1][k2]).  (tw): exp(-2 pi i k / 512),
 // k < 512; the stage factors exp(-2 pi i k1 n2 / N2) as [k1][n2]; exp(-2 pi i (k1 + K1 l) / N2) as
 // [k1][l], l < 64 (the factor w of a lane's register 0; register r has w . exp(-2 pi i r / 8)).
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ C<float> lane_read(unsigned byte_addr, C<float> q)
 {
     return {__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)byte_addr, __builtin_bit_cast(int, q.re))),
@@ -1673,15 +1674,15 @@ __device__ __forceinline__ C<float> cmla(C<float> acc, C<float> a, C<float> b)
 }
 
 // Rows a and b = K1 - a of one wave, spectra in, swapped filtered spectra out (the second
-// transform is swap . forward . swap).  he/g point at this lane's entry of row a; the partner
+// transform is swap . forward . swap).  hg_tab points at this lane's entry of row a; the partner
 // bin's factors need no tables: the taps are real, so Hev[N2-k] = conj Hev[k] and
 // (i/2) Hod[N2-k] = -conj((i/2) Hod[k]).
 template <int r>
-__device__ __forceinline__ void pair_step(C<float> *ua, C<float> *ub, const C<float> *he, const C<float> *g, C<float> w0,
-                                          unsigned rev)
+__device__ __forceinline__ void pair_step(C<float> *ua, C<float> *ub, const f32x4_t *hg_tab, C<float> w0, unsigned rev)
 {
     const C<float> A = ua[r], B = lane_read(rev, ub[7 - r]);
-    const C<float> hk = he[64 * r], gk = g[64 * r];
+    const f32x4_t hg = hg_tab[64 * r];  // both factors of a bin in one 16-byte load
+    const C<float> hk = {hg.x, hg.y}, gk = {hg.z, hg.w};
     const C<float> S = {A.re + B.re, A.im - B.im}, D = {A.re - B.re, A.im + B.im};
     const C<float> t = cmul(mul_w32<4 * r>(w0), D);
     const C<float> U = {S.re - t.re, S.im - t.im}, V = {S.re + t.re, S.im + t.im};
@@ -1692,35 +1693,36 @@ __device__ __forceinline__ void pair_step(C<float> *ua, C<float> *ub, const C<fl
     ub[7 - r] = lane_read(rev, C<float>{-q.im, q.re});  // conj(q), swapped
 }
 template <int... R>
-__device__ __forceinline__ void pair_rows(C<float> *ua, C<float> *ub, const C<float> *he, const C<float> *g, C<float> w0,
-                                          unsigned rev, std::integer_sequence<int, R...>)
+__device__ __forceinline__ void pair_rows(C<float> *ua, C<float> *ub, const f32x4_t *hg_tab, C<float> w0, unsigned rev,
+                                          std::integer_sequence<int, R...>)
 {
-    (pair_step<R>(ua, ub, he, g, w0, rev), ...);
+    (pair_step<R>(ua, ub, hg_tab, w0, rev), ...);
 }
 
 // A row that pairs with itself: the partner of register r is register 7-r of lane `from` / 4
 // (row 16: 63 - lane; row 0: (64 - lane) mod 64, and lane 0 pairs its own register r with
 // register (8 - r) mod 8).
 template <int r>
-__device__ __forceinline__ void self_step(C<float> *u, const C<float> *b, const C<float> *he, const C<float> *g, C<float> w0)
+__device__ __forceinline__ void self_step(C<float> *u, const C<float> *b, const f32x4_t *hg_tab, C<float> w0)
 {
     const C<float> A = u[r], B = b[r];
     const C<float> S = {A.re + B.re, A.im - B.im}, D = {A.re - B.re, A.im + B.im};
     const C<float> t = cmul(mul_w32<4 * r>(w0), D);
     const C<float> U = {S.re - t.re, S.im - t.im};
-    const C<float> zk = cmla(cmul(he[64 * r], A), g[64 * r], U);
+    const f32x4_t hg = hg_tab[64 * r];
+    const C<float> zk = cmla(cmul(C<float>{hg.x, hg.y}, A), C<float>{hg.z, hg.w}, U);
     u[r] = {zk.im, zk.re};
 }
 template <bool ROW0, int... R>
-__device__ __forceinline__ void pair_self(C<float> *u, const C<float> *he, const C<float> *g, C<float> w0, unsigned from,
-                                          bool lane0, std::integer_sequence<int, R...>)
+__device__ __forceinline__ void pair_self(C<float> *u, const f32x4_t *hg_tab, C<float> w0, unsigned from, bool lane0,
+                                          std::integer_sequence<int, R...>)
 {
     C<float> b[8];
     ((b[R] = lane_read(from, u[7 - R])), ...);
     if constexpr (ROW0) {
         ((b[R] = lane0 ? u[(8 - R) & 7] : b[R]), ...);
     }
-    (self_step<R>(u, b, he, g, w0), ...);
+    (self_step<R>(u, b, hg_tab, w0), ...);
 }
 
 template <int K1>
@@ -1817,12 +1819,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, K1 == 32
             row_passes_512(ub, wreg, tw1, tw2, lb);
             // the spectrum of the filtered block, from each bin and its partner
             asm volatile("" : "+v"(lh));
-            const C<T> *he = a.H + (size_t)NS * ra + lh, *heb = a.H + (size_t)NS * rb + lh;
+            const f32x4_t *hg_all = reinterpret_cast<const f32x4_t *>(a.H);
+            const f32x4_t *he = hg_all + (size_t)NS * ra + lh, *heb = hg_all + (size_t)NS * rb + lh;
             if (pr == 0 && wave == 0) {
-                pair_self<true>(ua, he, he + N2, tw_bin[64 * ra + lh], ((64u - lh) & 63u) * 4u, lh == 0, regs);
-                pair_self<false>(ub, heb, heb + N2, tw_bin[64 * rb + lh], (63u - lh) * 4u, false, regs);
+                pair_self<true>(ua, he, tw_bin[64 * ra + lh], ((64u - lh) & 63u) * 4u, lh == 0, regs);
+                pair_self<false>(ub, heb, tw_bin[64 * rb + lh], (63u - lh) * 4u, false, regs);
             } else {
-                pair_rows(ua, ub, he, he + N2, tw_bin[64 * ra + lh], (63u - lh) * 4u, regs);
+                pair_rows(ua, ub, he, tw_bin[64 * ra + lh], (63u - lh) * 4u, regs);
             }
             // ---- second transform: rows, stage factors, radix-K1 sum ----
             asm volatile("" : "+v"(la));

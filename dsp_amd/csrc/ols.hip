@@ -202,15 +202,15 @@ int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsi
             for (unsigned n2 = 0; n2 < NS; n2++) tw[NS + (size_t)k1 * NS + n2] = unit((unsigned long long)k1 * n2, N2);
         for (unsigned k1 = 0; k1 < K1; k1++)
             for (unsigned l = 0; l < 64; l++) tw[(size_t)NS + N2 + k1 * 64 + l] = unit(k1 + K1 * l, N2);
-        // [0] Hev / N2, [1] (i/2) Hod / N2: the transforms of the even and the odd taps, row by row
+        // {Hev / N2, (i/2) Hod / N2} per bin: the transforms of the even and the odd taps, row by row
         std::vector<std::complex<double>> he(N2, {0.0, 0.0}), ho(N2, {0.0, 0.0});
         for (unsigned j = 0; j < nh; j++) (j & 1 ? ho : he)[j / 2] = {(double)taps[j], 0.0};
         host_fft(he);
         host_fft(ho);
         for (unsigned k = 0; k < N2; k++) {
             const size_t at = (size_t)(k % K1) * NS + k / K1;
-            h[at] = {(float)(he[k].real() / N2), (float)(he[k].imag() / N2)};
-            h[N2 + at] = {(float)(-0.5 * ho[k].imag() / N2), (float)(0.5 * ho[k].real() / N2)};
+            h[2 * at] = {(float)(he[k].real() / N2), (float)(he[k].imag() / N2)};
+            h[2 * at + 1] = {(float)(-0.5 * ho[k].imag() / N2), (float)(0.5 * ho[k].real() / N2)};
         }
     } else if (rows) {
         for (unsigned k = 0; k < 1024; k++) {
