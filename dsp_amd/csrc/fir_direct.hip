@@ -872,73 +872,97 @@ int launch_mfma_t(FirParams<float> p, unsigned nchan, int bpc_default, hipStream
 // Requires nxx == nx, no flags, rows that start on 16-byte boundaries.  512 x 2^20 samples, 16 taps:
 // 0.732 ms against 0.752 for the tile kernel on the same box (5.88 against 5.72 TB/s); eight or
 // sixteen outputs per thread are slower (0.806, 1.50 ms: a lane's accesses are then 32 or 64 bytes apart).
-template <int NT>  // taps, rounded up to a multiple of four
-__global__ __launch_bounds__(256) void fir_stream_kernel(const FirParams<float> p, unsigned rows_per_y)
+// T = double: two outputs per lane, and -- the double path being bit-exact against the reference's
+// order of operations -- every product and every sum rounded on its own, taps in ascending order
+// (convolve, fft/src/main.c:193-204) or, DESC, descending (conv0's ascending input index,
+// convolution/main.c:27-32).
+template <typename T, int NT, bool DESC>  // NT: taps, rounded up to a multiple of four
+__global__ __launch_bounds__(256) void fir_stream_kernel(const FirParams<T> p, unsigned rows_per_y)
 {
+    constexpr int V = 16 / sizeof(T);  // outputs per lane: one 16-byte group
+    typedef T vec __attribute__((ext_vector_type(V)));
     const size_t row = (size_t)blockIdx.y + (size_t)rows_per_y * blockIdx.z;
-    const unsigned q = blockIdx.x * 256u + threadIdx.x;  // which four outputs of the row
-    const size_t i0 = (size_t)q * 4;
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;  // which group of the row
+    const size_t i0 = (size_t)q * V;
     // the ends of a row belong to fir_stream_edge_kernel: kept in here, the one wave per row that
     // meets them runs a chain of dependent loads and its workgroup outlives twenty others (rows
     // of 16384 samples: 593 Gsamples/s against 730 on rows of 2^20)
-    if (i0 < NT || i0 + 4 > p.nx) return;
-    float h[NT];
+    if (i0 < NT || i0 + V > p.nx) return;
+    T h[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) h[j] = p.taps[j];  // uniform: scalar loads (zero-padded past nh)
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(p.x + row * p.x_stride + i0 - NT);
-    float w[NT + 4];
+    const vec *src = reinterpret_cast<const vec *>(p.x + row * p.x_stride + i0 - NT);
+    T w[NT + V];
 #pragma unroll
-    for (int k = 0; k < NT / 4 + 1; k++) {
-        const f32x4 v = src[k];
-        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    for (int k = 0; k < NT / V + 1; k++) {
+        const vec v = src[k];
+#pragma unroll
+        for (int e = 0; e < V; e++) w[V * k + e] = v[e];
     }
-    f32x4 acc;
+    vec acc;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-        float a = 0.f;
+    for (int o = 0; o < V; o++) {
+        T a = 0;
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(h[j], w[NT + o - j], a);  // descending tap index, as the tile kernel sums
+            for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(h[j], w[NT + o - j], a);  // descending tap index, as the tile kernel sums
+        } else if constexpr (DESC) {
+#pragma unroll
+            for (int j = NT - 1; j >= 0; j--) a = a + h[j] * w[NT + o - j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; j++) a = a + h[j] * w[NT + o - j];
+        }
         acc[o] = a;
     }
-    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(p.y + row * p.y_stride + i0));
+    __builtin_nontemporal_store(acc, reinterpret_cast<vec *>(p.y + row * p.y_stride + i0));
 }
 
-// The groups of four outputs the kernel above leaves out: the first NT/4 of every row (history or
-// zeros before the row) and the last one of a row whose length is not a multiple of four.  One
+// The groups of outputs the kernel above leaves out: the first NT/V of every row (history or
+// zeros before the row) and the last one of a row whose length is not a multiple of V.  One
 // lane each, element by element, every load unconditional from a clamped index.
-template <int NT>
-__global__ __launch_bounds__(64) void fir_stream_edge_kernel(const FirParams<float> p, unsigned nchan)
+template <typename T, int NT, bool DESC>
+__global__ __launch_bounds__(64) void fir_stream_edge_kernel(const FirParams<T> p, unsigned nchan)
 {
-    constexpr unsigned PER_ROW = NT / 4 + 1;
+    constexpr int V = 16 / sizeof(T);
+    constexpr unsigned PER_ROW = NT / V + 1;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     const size_t row = t / PER_ROW;
     const unsigned e = (unsigned)(t - row * PER_ROW);
     if (row >= nchan) return;
     const long nx = p.nx, nh = p.nh;
-    const long qlast = (nx - 1) / 4;
+    const long qlast = (nx - 1) / V;
     long q = e;
-    if (e == NT / 4) {
-        if (!(nx & 3) || qlast < NT / 4) return;  // the row ends on a whole group, or its last group is one of the first
+    if (e == NT / V) {
+        if (!(nx % V) || qlast < NT / V) return;  // the row ends on a whole group, or its last group is one of the first
         q = qlast;
     }
-    const long i0 = 4 * q;
+    const long i0 = V * q;
     if (i0 >= nx) return;
-    const float *x = p.x + row * p.x_stride;
-    const float *hist = (p.hist && nh > 1) ? p.hist + row * p.hist_stride : nullptr;
-    float w[NT + 4];
+    const T *x = p.x + row * p.x_stride;
+    const T *hist = (p.hist && nh > 1) ? p.hist + row * p.hist_stride : nullptr;
+    T w[NT + V];
 #pragma unroll
-    for (int k = 0; k < NT + 4; k++) {
+    for (int k = 0; k < NT + V; k++) {
         const long s = i0 - NT + k, u = nh - 1 + s;  // position in the row, in the history
-        const float vx = x[s < 0 ? 0 : (s >= nx ? nx - 1 : s)];
-        const float vh = hist ? hist[u < 0 ? 0 : (u > nh - 2 ? nh - 2 : u)] : 0.f;
-        w[k] = s >= 0 ? (s < nx ? vx : 0.f) : (s >= 1 - nh ? vh : 0.f);
+        const T vx = x[s < 0 ? 0 : (s >= nx ? nx - 1 : s)];
+        const T vh = hist ? hist[u < 0 ? 0 : (u > nh - 2 ? nh - 2 : u)] : (T)0;
+        w[k] = s >= 0 ? (s < nx ? vx : (T)0) : (s >= 1 - nh ? vh : (T)0);
     }
-    float *y = p.y + row * p.y_stride;
+    T *y = p.y + row * p.y_stride;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-        float a = 0.f;
+    for (int o = 0; o < V; o++) {
+        T a = 0;
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(p.taps[j], w[NT + o - j], a);
+            for (int j = NT - 1; j >= 0; j--) a = __builtin_fmaf(p.taps[j], w[NT + o - j], a);
+        } else if constexpr (DESC) {
+#pragma unroll
+            for (int j = NT - 1; j >= 0; j--) a = a + p.taps[j] * w[NT + o - j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; j++) a = a + p.taps[j] * w[NT + o - j];
+        }
         if (i0 + o < nx) y[i0 + o] = a;
     }
 }
@@ -953,52 +977,62 @@ constexpr unsigned kStreamMaxTaps = 16;
 constexpr unsigned kStreamMaxTapsShortRows = 32;
 
 // nullptr-safe test of what the stream kernel needs; the caller falls back to the tile kernel otherwise
-bool stream_applies(const FirParams<float> &p)
+template <typename T>
+bool stream_applies(const FirParams<T> &p)
 {
+    constexpr unsigned V = 16 / sizeof(T);
     const char *env = getenv("DSPMI_FIR_STREAM");  // 0: keep the tile kernel (A/B)
     if (env && !atoi(env)) return false;
-    const bool taps_ok = p.nh <= kStreamMaxTaps || (p.nh <= kStreamMaxTapsShortRows && p.nx < (p.nh <= 24 ? 4096u : 2048u));
-    return taps_ok && p.nhp >= ((p.nh + 3) & ~3u) && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & 3) &&
-           !(p.y_stride & 3) && !((reinterpret_cast<size_t>(p.x) | reinterpret_cast<size_t>(p.y)) & 15);
+    // In double every tap costs a multiplication and an addition per output (rounded separately),
+    // so the stream kernel's range is shorter: 256 x 2^20 samples, 4 taps 0.673 ms against 0.881
+    // for the tile kernel (6.4 against 4.9 TB/s), 8 taps 0.724 / 0.885, 12 taps 0.853 / 0.890, 16
+    // taps 1.03 / 0.895; on rows of 1024 it is ahead up to 24 taps, on rows of 256 (2048-output
+    // tiles seven eighths empty) three to four times faster for every count up to 32.
+    const bool taps_ok = sizeof(T) == 4 ? p.nh <= kStreamMaxTaps || (p.nh <= kStreamMaxTapsShortRows && p.nx < (p.nh <= 24 ? 4096u : 2048u))
+                                        : p.nh <= 12 || (p.nh <= 24 && p.nx < 2048u) || (p.nh <= kStreamMaxTapsShortRows && p.nx < 512u);
+    return taps_ok && p.nhp >= ((p.nh + 3) & ~3u) && p.flags == 0 && p.nxx == p.nx && p.nx >= 64 && !(p.x_stride & (V - 1)) &&
+           !(p.y_stride & (V - 1)) && !((reinterpret_cast<size_t>(p.x) | reinterpret_cast<size_t>(p.y)) & 15);
 }
 
-template <int NT>
-int launch_stream_t(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
+template <typename T, int NT, bool DESC>
+int launch_stream_t(const FirParams<T> &p, unsigned nchan, hipStream_t stream)
 {
-    const unsigned quads = (unsigned)(((unsigned long long)p.nx + 3) / 4);
-    const unsigned gx = (quads + 255) / 256;
+    constexpr unsigned V = 16 / sizeof(T);
+    const unsigned groups = (unsigned)(((unsigned long long)p.nx + V - 1) / V);
+    const unsigned gx = (groups + 255) / 256;
     const unsigned gy = nchan < 65535u ? nchan : 65535u;
     // rows beyond 65535 go into the grid's third dimension; the remainder is a second launch
     const unsigned gz = nchan / gy;
-    hipLaunchKernelGGL(fir_stream_kernel<NT>, dim3(gx, gy, gz), dim3(256), 0, stream, p, gy);
+    hipLaunchKernelGGL((fir_stream_kernel<T, NT, DESC>), dim3(gx, gy, gz), dim3(256), 0, stream, p, gy);
     DSPMI_HIP(hipGetLastError());
     const unsigned done = gy * gz;
     if (done < nchan) {
-        FirParams<float> r = p;
+        FirParams<T> r = p;
         r.x += (size_t)done * p.x_stride;
         r.y += (size_t)done * p.y_stride;
         if (r.hist) r.hist += (size_t)done * p.hist_stride;
-        hipLaunchKernelGGL(fir_stream_kernel<NT>, dim3(gx, nchan - done, 1), dim3(256), 0, stream, r, nchan - done);
+        hipLaunchKernelGGL((fir_stream_kernel<T, NT, DESC>), dim3(gx, nchan - done, 1), dim3(256), 0, stream, r, nchan - done);
         DSPMI_HIP(hipGetLastError());
     }
-    const unsigned long long edges = (unsigned long long)nchan * (NT / 4 + 1);
-    hipLaunchKernelGGL(fir_stream_edge_kernel<NT>, dim3((unsigned)((edges + 63) / 64)), dim3(64), 0, stream, p, nchan);
+    const unsigned long long edges = (unsigned long long)nchan * (NT / V + 1);
+    hipLaunchKernelGGL((fir_stream_edge_kernel<T, NT, DESC>), dim3((unsigned)((edges + 63) / 64)), dim3(64), 0, stream, p, nchan);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
 
-int launch_stream(const FirParams<float> &p, unsigned nchan, hipStream_t stream)
+template <typename T, bool DESC>
+int launch_stream(const FirParams<T> &p, unsigned nchan, hipStream_t stream)
 {
     static_assert(kStreamMaxTapsShortRows == 32, "one instance per multiple of four taps");
     switch ((p.nh + 3) / 4) {
-    case 0: case 1: return launch_stream_t<4>(p, nchan, stream);
-    case 2: return launch_stream_t<8>(p, nchan, stream);
-    case 3: return launch_stream_t<12>(p, nchan, stream);
-    case 4: return launch_stream_t<16>(p, nchan, stream);
-    case 5: return launch_stream_t<20>(p, nchan, stream);
-    case 6: return launch_stream_t<24>(p, nchan, stream);
-    case 7: return launch_stream_t<28>(p, nchan, stream);
-    default: return launch_stream_t<32>(p, nchan, stream);
+    case 0: case 1: return launch_stream_t<T, 4, DESC>(p, nchan, stream);
+    case 2: return launch_stream_t<T, 8, DESC>(p, nchan, stream);
+    case 3: return launch_stream_t<T, 12, DESC>(p, nchan, stream);
+    case 4: return launch_stream_t<T, 16, DESC>(p, nchan, stream);
+    case 5: return launch_stream_t<T, 20, DESC>(p, nchan, stream);
+    case 6: return launch_stream_t<T, 24, DESC>(p, nchan, stream);
+    case 7: return launch_stream_t<T, 28, DESC>(p, nchan, stream);
+    default: return launch_stream_t<T, 32, DESC>(p, nchan, stream);
     }
 }
 
@@ -1402,7 +1436,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         if (pl->half_tab && pl->half_exec && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
-            if (!pl->pinned && stream_applies(p)) return launch_stream(p, nchan, s);
+            if (!pl->pinned && stream_applies(p)) return launch_stream<float, false>(p, nchan, s);
             return launch_mfma(p, nchan, s);
         }
         if (pl->variant == V_F32_SHORT) {
@@ -1412,6 +1446,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
         p.tiles_per_chan = (unsigned)(((unsigned long long)nxx + 4095) / 4096);
         return launch<float, 8, 2, 16, false, false>(p, nchan, s);
     } else {
+        if (stream_applies(p)) return desc ? launch_stream<double, true>(p, nchan, s) : launch_stream<double, false>(p, nchan, s);
         p.tiles_per_chan = (unsigned)(((unsigned long long)nxx + 2047) / 2048);
         if (desc) return launch<double, 4, 2, 8, true, true>(p, nchan, s);
         return launch<double, 4, 2, 8, true, false>(p, nchan, s);

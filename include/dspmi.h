@@ -88,6 +88,9 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  * DSPMI_FIR_VARIANT = mfma | f16 | bf16 | ols in the environment at creation pins the f32 kernel,
  * the f16 kernel, its three-part bf16 sibling (no scale, full f32 exponent range) or overlap-save. */
 int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device);
+/* An f64 plan sums in double with every product and every sum rounded on its own, in the
+ * reference's order (bit for bit conv0 / conv1 / convolve); filters of up to 12 taps (more on
+ * rows shorter than 2048 samples) take the same tile-free kernel as short f32 filters. */
 int dspmi_fir_create_f64(dspmi_fir_t *plan, const double *taps, unsigned nh, int device);
 int dspmi_fir_destroy(dspmi_fir_t plan);
 

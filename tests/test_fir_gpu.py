@@ -526,3 +526,32 @@ def test_short_filter_stream_over_many_rows():
     for c in (0, 1, 65534, 65535, 65536, 70000):
         want = oracle.fir_batch_f32(x[c:c + 1], h, nx)[0]
         assert rel_l2(y[c], want) <= TOL_FIR, c
+
+
+@pytest.mark.parametrize("nh", [1, 3, 9, 12, 16, 21, 32])
+@pytest.mark.parametrize("nx,nchan", [(64, 1), (65, 3), (300, 4), (1001, 4), (5001, 2), (70000, 2)])
+def test_short_filters_as_a_stream_in_double(nh, nx, nchan, monkeypatch):
+    """The double-precision plans behind the host routines run short filters through the same
+    kernel without tiles (two outputs per lane, every product and sum rounded on its own in the
+    reference's order): bit for bit the tile kernel's outputs (DSPMI_FIR_STREAM=0) with carried
+    history, and bit for bit the oracle's conv0 / conv1 / convolve through the host routines."""
+    rng = np.random.default_rng(nh * 100 + nx)
+    h = rng.uniform(-1, 1, nh)
+    stride = (nx + 1) & ~1                      # rows start on 16-byte boundaries
+    buf = torch.zeros((nchan, stride), dtype=torch.float64, device="cuda")
+    x = rng.uniform(-1, 1, (nchan, nx))
+    buf[:, :nx] = torch.from_numpy(x).cuda()
+    hist = torch.from_numpy(rng.uniform(-1, 1, (nchan, nh - 1))).cuda() if nh > 1 else None
+    plan = dsp_amd.FirPlan(h, "f64")
+    ybuf = torch.zeros_like(buf)
+    a = plan.exec(buf[:, :nx], nx, y=ybuf[:, :nx], hist=hist).cpu().numpy().copy()
+    monkeypatch.setenv("DSPMI_FIR_STREAM", "0")
+    b = plan.exec(buf[:, :nx], nx, y=ybuf[:, :nx], hist=hist).cpu().numpy().copy()
+    monkeypatch.delenv("DSPMI_FIR_STREAM")
+    assert np.array_equal(a, b)
+    if nchan == 2:
+        xs = x[0]
+        assert np.array_equal(dsp_amd.conv0(xs, h), oracle.conv0(xs, h))
+        assert np.array_equal(dsp_amd.conv1(xs, h), oracle.conv1(xs, h))
+        assert np.array_equal(dsp_amd.convolve(xs, h, nx), oracle.convolve(xs, h, nx))
+        assert np.array_equal(dsp_amd.convolve_alloc(xs, h), oracle.convolve(xs, h))
