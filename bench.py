@@ -107,16 +107,18 @@ def uniform(shape, seed, device):
 
 
 def timed(fn, steps, warmup, world):
-    """Returns (wall seconds over `steps`, max over ranks; event ms per launch on this rank)."""
+    """Returns (wall seconds over `steps`, max over ranks; mean event ms per launch on this rank;
+    median of the per-launch event times).  The events are recorded on torch's current stream,
+    which is the stream every launch is given (dsp_amd.lib passes torch.cuda.current_stream())."""
     for _ in range(warmup):
         fn()
     barrier(world)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
+    ev[0].record()
+    for i in range(steps):
         fn()
-    e1.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
     barrier(world)
     dt = time.perf_counter() - t0
@@ -124,7 +126,9 @@ def timed(fn, steps, warmup, world):
         t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    return dt, e0.elapsed_time(e1) / steps
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    median = per[steps // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
+    return dt, ev[0].elapsed_time(ev[steps]) / steps, median
 
 
 # ---------------------------------------------------------------------------
@@ -326,6 +330,16 @@ def make_chain(args, rank):
     return step, info, (gen, x, fir, fft, y, ps, hist)
 
 
+def flops_key(info):
+    """`gflops` where the kernel executes the counted operations (the direct form's 2*nh per
+    output in f32, or the transform's nominal 5*N*log2(N)); the f16 matrix-pipe kernel, the
+    overlap-save kernels and the chain compute the same outputs another way, so their figure is
+    what the direct form WOULD have executed."""
+    k = info["kernel"]
+    executes = k.startswith("fft_") or "mfma16x16x4" in k or "stream" in k
+    return "gflops" if executes else "direct_form_equivalent_gflops"
+
+
 def measured_traffic(info):
     """HBM bytes per launch of this workload from the committed rocprofv3 PMC passes
     (profiles/traffic.json, filled from separate --pmc FETCH_SIZE / WRITE_SIZE runs), or None
@@ -339,13 +353,22 @@ def measured_traffic(info):
     return ent["hbm_bytes"] if ent else None
 
 
-def roofline(info, ms_per_launch):
+TRAFFIC_SOURCE = ("profiles/traffic.json: a table filled from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                  "of this workload (not collected in this run)")
+
+
+def roofline(info, ms_per_launch, ms_median=None):
+    """`achieved` uses the mean event time per launch over the timed region; the median of the
+    per-launch event times is reported beside it (`launch_ms_median`)."""
     sec = ms_per_launch * 1e-3
+    traffic = measured_traffic(info)
+    common = {"launch_ms": round(ms_per_launch, 4),
+              "launch_ms_median": None if ms_median is None else round(ms_median, 4),
+              "traffic": traffic, "traffic_source": TRAFFIC_SOURCE if traffic is not None else None}
     if info["bound"] == "hbm":
         achieved = info["bytes_per_unit"] * info["units"] / sec / 1e9
         out = {"bound": "hbm", "kernel": info["kernel"], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(info),
-               "launch_ms": round(ms_per_launch, 4),
+               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), **common,
                "algorithmic_bytes_per_launch": info["bytes_per_unit"] * info["units"]}
         if info["kernel"].startswith("fir_f32_") and "mfma16x16x32" in info["kernel"] and info.get("nh", 0) * 2.0 / 8.0 > FP32_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
             # a direct-form kernel past the ridge of the f32 vector roof: that fraction too (it can exceed 1, the
@@ -356,8 +379,7 @@ def roofline(info, ms_per_launch):
         return out
     achieved = info["flop_per_unit"] * info["units"] / sec / 1e12
     out = {"bound": "mfma", "dtype_peak": "f32 MFMA dense = FP32 vector peak", "kernel": info["kernel"], "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS,
-           "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": measured_traffic(info),
-           "launch_ms": round(ms_per_launch, 4),
+           "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4), **common,
            "hbm_frac": round(info["bytes_per_unit"] * info["units"] / sec / 1e9 / HBM_PEAK_GBS, 4),
            "algorithmic_flop_per_launch": info["flop_per_unit"] * info["units"]}
     if "note" in info:
@@ -568,10 +590,10 @@ def main():
         args.warmup = 200    # 0.2 ms launches: the clocks settle over some tens of milliseconds of work
     if args.workload in ("chain", "fir16", "fir127", "fir127_direct") and args.warmup < 15:
         args.warmup = 15
-    dt, ms_launch = timed(fn, args.steps, args.warmup, world)
+    dt, ms_launch, ms_median = timed(fn, args.steps, args.warmup, world)
     local_ms = None
     if "local_only" in info:
-        _, local_ms = timed(info.pop("local_only"), args.steps, 1, world)
+        _, local_ms, _ = timed(info.pop("local_only"), args.steps, 1, world)
     units_total = info["units"] * world * args.steps
     gflops = info["flop_per_unit"] * units_total / dt / 1e9
     gsamples = info["samples_per_unit"] * units_total / dt / 1e9
@@ -598,12 +620,12 @@ def main():
             # Enough launches ahead of the timed ones that the clocks have settled (some tens of
             # milliseconds of work: the first launches after a pause run 10-15 % slower), as the
             # headline's 200 launches do for themselves.
-            d2, ms2 = timed(f2, nsec, nwarm, 1)
+            d2, ms2, med2 = timed(f2, nsec, nwarm, 1)
             ent = {"workload": i2["workload"],
                    "gsamples_per_s": round(i2["units"] * nsec / d2 / 1e9, 2),
-                   "gflops": round(i2["flop_per_unit"] * i2["units"] * nsec / d2 / 1e9, 1),
+                   flops_key(i2): round(i2["flop_per_unit"] * i2["units"] * nsec / d2 / 1e9, 1),
                    "ms_per_step": round(d2 / nsec * 1e3, 4),
-                   "roofline": roofline(i2, ms2)}
+                   "roofline": roofline(i2, ms2, med2)}
             if "fir_fft_ms" in i2:
                 ent["fir_fft_stages_only_ms"] = round(i2["fir_fft_ms"], 3)
             secondary.append(ent)
@@ -641,8 +663,8 @@ def main():
                        "unit_name": info["unit_name"],
                        "sharding": ("one signal cut into halo'd output segments, one all_gather of the outputs"
                                     if args.workload == "ols8191_split" else "frames/channels split across ranks, no collective")},
-            "gsamples_per_s": round(gsamples, 2), "gflops": round(gflops, 1),
-            "roofline": roofline(info, ms_launch),
+            "gsamples_per_s": round(gsamples, 2), flops_key(info): round(gflops, 1),
+            "roofline": roofline(info, ms_launch, ms_median),
             "cpu_baseline": cpu,
             "secondary": secondary,
         }
