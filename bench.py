@@ -62,6 +62,8 @@ def parse():
                                                              "ols8191_split", "chain"])
     ap.add_argument("--ols-n", type=int, default=0, help="8191-tap overlap-save: transform length (0 = the plan's choice)")
     ap.add_argument("--chain-two-kernels", action="store_true", help="chain workload: FIR and real transform as two kernels (A/B)")
+    ap.add_argument("--chain-separate-generator", action="store_true",
+                    help="chain workload: the generator as a kernel of its own in front of the fused filter + spectrum kernel (A/B)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="FFT frames per GPU")
     ap.add_argument("--channels", type=int, default=512, help="FIR channels per GPU (4096 / 8 GPUs)")
     ap.add_argument("--samples", type=int, default=1 << 20, help="FIR samples per channel")
@@ -293,6 +295,11 @@ def make_chain(args, rank):
     hist = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
 
     fused = nh <= 305 and not args.chain_two_kernels
+    one_kernel = fused and not args.chain_separate_generator
+    hists = [hist, torch.empty_like(hist)]
+    work = None
+    if one_kernel:
+        work = torch.empty((dsp_amd.lib().dspmi_tone_fir_spectrum_work_bytes(chunk, nchan, gen.ntone),), dtype=torch.uint8, device="cuda")
 
     def filter_and_transform():
         if fused:
@@ -304,8 +311,14 @@ def make_chain(args, rank):
 
     def step():
         for _ in range(nchunk):
-            gen.read(chunk, out=x)
-            filter_and_transform()
+            if one_kernel:
+                # generator -> FIR -> r2c -> |X| / sum in one kernel: neither x nor y reaches HBM; the
+                # kernel leaves the chunk's last nh-1 samples for the next call
+                fir.tone_spectrum(fft, gen, chunk, hist=hists[0], hist_out=hists[1], out=ps, work=work)
+                hists.reverse()
+            else:
+                gen.read(chunk, out=x)
+                filter_and_transform()
 
     gen.read(chunk, out=x)
     for _ in range(2):
@@ -318,16 +331,23 @@ def make_chain(args, rank):
     fir_fft_ms = (time.perf_counter() - t0) * 1e3 / 3
 
     units = nchan * chunk * nchunk
-    info = dict(kernel=("tonegen + fir_spectrum(f16x2 matrix pipe, %d taps, n%d)" % (nh, nfft)) if fused else
-                "tonegen + %s + r2c_spectrum(%s)" % (fir.variant, fft.variant), units=units, unit_name="samples",
+    if one_kernel:
+        kernel = "tone_fir_spectrum(tones + f16x2 matrix pipe, %d taps, n%d)" % (nh, nfft)
+        how = ("one kernel: the samples are generated into the filter's staging registers and the filtered samples stay on "
+               "chip, so the kernel itself moves only the 2 B of spectrum per sample (plus ~1.5 % of tables)")
+    elif fused:
+        kernel = "tonegen + fir_spectrum(f16x2 matrix pipe, %d taps, n%d)" % (nh, nfft)
+        how = "the generator hands its samples on through HBM (4 B written + 4 B read per sample), the filtered samples stay on chip"
+    else:
+        kernel = "tonegen + %s + r2c_spectrum(%s)" % (fir.variant, fft.variant)
+        how = "the stages hand their results on through HBM, which the roof does not allow for"
+    info = dict(kernel=kernel, units=units, unit_name="samples",
                 nh=nh, flop_per_unit=2.0 * nh + 2.5 * math.log2(nfft), bytes_per_unit=4.0 + 2.0, bound="hbm",
                 samples_per_unit=1, fir_fft_ms=fir_fft_ms,
-                note="algorithmic bytes: 4 B per generated sample + 2 B of spectrum per sample (N/2+1 floats per N samples); "
-                     + ("the generator hands its samples on through HBM (4 B written + 4 B read per sample), the filtered samples stay on chip"
-                        if fused else "the stages hand their results on through HBM, which the roof does not allow for"),
+                note="algorithmic bytes: 4 B per generated sample + 2 B of spectrum per sample (N/2+1 floats per N samples); " + how,
                 workload="chain: tones -> %d-tap FIR -> N=%d r2c -> |X|/sum, %d channels x %d samples in %d chunks"
                          % (nh, nfft, nchan, chunk * nchunk, nchunk))
-    return step, info, (gen, x, fir, fft, y, ps, hist)
+    return step, info, (gen, x, fir, fft, y, ps, hists, work)
 
 
 def flops_key(info):

@@ -82,7 +82,33 @@ struct FirSpectrumLaunch {
     unsigned nbin;
     int mode;
     float scale;
+    // tone_slots > 0 (2 or 4): the rows are generated inside the kernel from these tables
+    // (tone_chain_prepare, spectrum.hip); x then holds the generator's own output for the tiles
+    // the tables mark as hard, and hist_out receives every row's last nh-1 samples
+    int tone_slots;
+    const double *lane_tab, *tile_tab;
+    const unsigned *hard;
+    float *hist_out;
+    size_t hist_out_stride;
 };
 int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s);
+
+
+// Tables for the tone source of the fused FIR + spectrum kernel (layouts in fir_half.h), one
+// call's worth: running angles w[nchan][ntone] (read, not advanced), increments dw, amplitudes
+// and phases (cosine form) or unit sines (use_sin).  A window covers samples
+// [4096 tile - lead, 4096 tile + 4096) of a row of nx samples.  Tiles marked hard are generated
+// into spill[chan][nx] by the stand-alone generator.  slots: 2 or 4 (>= ntone).
+struct ToneChainTables {
+    double *lane_tab, *tile_tab;
+    unsigned *hard;
+    float *spill;
+};
+size_t tone_chain_work_bytes(unsigned nx, unsigned nchan, int slots);
+ToneChainTables tone_chain_carve(void *work, unsigned nx, unsigned nchan, int slots);
+int tone_chain_prepare(const ToneChainTables &tab, unsigned nx, unsigned nchan, unsigned ntone, int slots, unsigned lead,
+                       const double *w, const double *dw, const double *amp, const double *phi, int use_sin, hipStream_t s);
+// w[i] <- the running angle after n more samples
+int tone_chain_finish(double *w, const double *dw, unsigned n, unsigned nseq, hipStream_t s);
 
 }  // namespace dspmi

@@ -968,6 +968,72 @@ int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned
     return dspmi::fir_spectrum_launch(a, static_cast<hipStream_t>(stream));
 }
 
+size_t dspmi_tone_fir_spectrum_work_bytes(unsigned nx, unsigned nchan, unsigned ntone)
+{
+    if (ntone == 0 || ntone > 4 || nx % 4096) return 0;
+    return dspmi::tone_chain_work_bytes(nx, nchan, ntone <= 2 ? 2 : 4);
+}
+
+int dspmi_tone_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode, float scale, unsigned nx,
+                                unsigned nchan, unsigned ntone, double *w, const double *dw, const double *amp, const double *phi,
+                                int use_sin, const float *hist, size_t hist_stride, float *hist_out, size_t hist_out_stride,
+                                void *work, size_t work_bytes, void *stream)
+{
+    if (!fir || !fft) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: null plan");
+    if (int rc = dspmi::check_device(fft->device, "tone_fir_spectrum")) return rc;
+    dspmi::FirSpectrumLaunch a{};
+    int fir_device = -1;
+    if (int rc = dspmi::fir_half_images(fir, &a.tap_images, &a.tap_unscale, &a.slices, &a.nh, &fir_device)) return rc;
+    if (fir_device != fft->device) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: the two plans belong to different devices");
+    if (fft->precision != DSPMI_F32 || fft->n != 4096 || !fused_real(fft))
+        return dspmi::fail(DSPMI_ENOSYS, "tone_fir_spectrum: needs an f32 transform plan of 4096 points");
+    if (ntone == 0 || ntone > 4)
+        return dspmi::fail(DSPMI_ENOSYS, "tone_fir_spectrum: 1..4 tones per channel (got %u); generate, then dspmi_fir_spectrum_f32", ntone);
+    if (nchan == 0 || nx == 0) return DSPMI_OK;
+    if (nx % 4096) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: rows must hold whole frames of 4096 samples");
+    if (!ps || !w || !dw || !work || (!use_sin && (!amp || !phi))) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: null buffer");
+    if (hist && hist_stride + 1 < a.nh) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: hist_stride < nh-1");
+    if (hist_out && hist_out_stride + 1 < a.nh) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: hist_out_stride < nh-1");
+    if (mode < 0 || mode > 2) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: mode must be 0, 1 or 2");
+    if (nbin != 2048 && nbin != 2049) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: nbin must be 2048 or 2049");
+    if (reinterpret_cast<uintptr_t>(work) & 255) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: work space must be 256-byte aligned");
+    const int slots = ntone <= 2 ? 2 : 4;
+    const size_t need = dspmi::tone_chain_work_bytes(nx, nchan, slots);
+    if (work_bytes < need)
+        return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: work space of %zu bytes, %zu needed", work_bytes, need);
+    const size_t frames = (size_t)nchan * (nx / 4096);
+    if (ranges_overlap(work, need, ps, frames * nbin * sizeof(float)))
+        return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: the spectrum buffer overlaps the work space");
+    if (hist && hist_out && a.nh > 1 &&
+        ranges_overlap(hist, ((size_t)(nchan - 1) * hist_stride + a.nh - 1) * sizeof(float), hist_out,
+                       ((size_t)(nchan - 1) * hist_out_stride + a.nh - 1) * sizeof(float)))
+        return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: hist_out overlaps hist (the rows' first and last tiles run concurrently)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dspmi::ToneChainTables tab = dspmi::tone_chain_carve(work, nx, nchan, slots);
+    const unsigned lead = 32u * (unsigned)a.slices - 16u;   // window positions ahead of a tile's first output
+    if (int rc = dspmi::tone_chain_prepare(tab, nx, nchan, ntone, slots, lead, w, dw, amp, phi, use_sin, s)) return rc;
+    a.x = tab.spill;
+    a.x_stride = nx;
+    a.hist = hist;
+    a.hist_stride = hist_stride;
+    a.nx = nx;
+    a.nchan = nchan;
+    a.tw_half = fft->tw_half;
+    a.tw_full = fft->tw_n;
+    a.ps = ps;
+    a.nbin = nbin;
+    a.mode = mode;
+    a.scale = scale;
+    a.tone_slots = slots;
+    a.lane_tab = tab.lane_tab;
+    a.tile_tab = tab.tile_tab;
+    a.hard = tab.hard;
+    a.hist_out = hist_out;
+    a.hist_out_stride = hist_out_stride;
+    if (int rc = dspmi::fir_spectrum_launch(a, s)) return rc;
+    return dspmi::tone_chain_finish(w, dw, nx, nchan * ntone, s);
+}
+
 int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float *ps, size_t batch, unsigned nbin, int mode,
                                       float scale, void *stream)
 {

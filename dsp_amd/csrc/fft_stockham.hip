@@ -977,23 +977,79 @@ __global__ __launch_bounds__(256) void fir_spectrum_kernel(const FirParams<float
     sink.mode = mode;
     sink.scale = scale;
     sink.frame = 0;
-    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink);
+    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
+}
+
+// The same kernel with the tone generator in front (tonegen/tonegen.c:25-40 -> do_fir ->
+// do_power_spectrum): the samples are computed into the walker's staging registers
+// (ToneSource, fir_half.h) instead of being read, so a chunk of the chain costs the 2 bytes
+// of spectrum per sample and nothing else in HBM.
+template <int NS, int MAXT>
+__global__ __launch_bounds__(256) void tone_fir_spectrum_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab,
+                                                                float tap_unscale, const C<float> *__restrict__ tw,
+                                                                const C<float> *__restrict__ tw2n, float *ps, unsigned nbin,
+                                                                int mode, float scale, const ToneSource<MAXT> src)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr size_t kPlanes = half_lds_bytes(NS);
+    SpectrumSink<NS> sink;
+    sink.img = reinterpret_cast<C<float> *>(smem_raw + kPlanes);
+    setup_lds_twiddles_split<float, 2048, 256, 1, 8, 8, kPlanes + kSpectrumImageBytes>(smem_raw, tw, sink.tw1, sink.tw2, sink.tw3);
+    sink.tw = tw;
+    sink.tw2n = tw2n;
+    sink.scratch = reinterpret_cast<float *>(smem_raw + kPlanes + kSpectrumImageBytes +
+                                             lds_twiddle_entries(3, 8, 8, 8, 4, 2048) * sizeof(C<float>));
+    sink.ps = ps;
+    sink.nbin = nbin;
+    sink.frames_per_chan = p.tiles_per_chan;
+    sink.mode = mode;
+    sink.scale = scale;
+    sink.frame = 0;
+    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink, src);
+}
+
+template <int NS, int MAXT>
+int launch_fir_spectrum_t(const FirParams<float> &p, const dspmi::FirSpectrumLaunch &a, unsigned blocks, hipStream_t s)
+{
+    static dspmi::PerDeviceOnce attr;
+    if constexpr (MAXT == 0) {
+        auto kern = fir_spectrum_kernel<NS>;
+        if (attr.pending()) {
+            DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr.mark();
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), fir_spectrum_lds_bytes(NS), s, p, static_cast<const u32x4 *>(a.tap_images),
+                           a.tap_unscale, static_cast<const C<float> *>(a.tw_half), static_cast<const C<float> *>(a.tw_full), a.ps,
+                           a.nbin, a.mode, a.scale);
+    } else {
+        auto kern = tone_fir_spectrum_kernel<NS, MAXT>;
+        if (attr.pending()) {
+            DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr.mark();
+        }
+        ToneSource<MAXT> src;
+        src.lane_tab = a.lane_tab;
+        src.tile_tab = a.tile_tab;
+        src.hard = a.hard;
+        src.hist_out = a.hist_out;
+        src.hist_out_stride = a.hist_out_stride;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), fir_spectrum_lds_bytes(NS), s, p, static_cast<const u32x4 *>(a.tap_images),
+                           a.tap_unscale, static_cast<const C<float> *>(a.tw_half), static_cast<const C<float> *>(a.tw_full), a.ps,
+                           a.nbin, a.mode, a.scale, src);
+    }
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
 }
 
 template <int NS>
-int launch_fir_spectrum_t(const FirParams<float> &p, const dspmi::FirSpectrumLaunch &a, unsigned blocks, hipStream_t s)
+int launch_fir_spectrum_n(const FirParams<float> &p, const dspmi::FirSpectrumLaunch &a, unsigned blocks, hipStream_t s)
 {
-    auto kern = fir_spectrum_kernel<NS>;
-    static dspmi::PerDeviceOnce attr;
-    if (attr.pending()) {
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr.mark();
+    switch (a.tone_slots) {
+    case 0: return launch_fir_spectrum_t<NS, 0>(p, a, blocks, s);
+    case 2: return launch_fir_spectrum_t<NS, 2>(p, a, blocks, s);
+    case 4: return launch_fir_spectrum_t<NS, 4>(p, a, blocks, s);
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), fir_spectrum_lds_bytes(NS), s, p, static_cast<const u32x4 *>(a.tap_images),
-                       a.tap_unscale, static_cast<const C<float> *>(a.tw_half), static_cast<const C<float> *>(a.tw_full), a.ps,
-                       a.nbin, a.mode, a.scale);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
+    return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: no kernel for %d tone slots", a.tone_slots);
 }
 
 // ---------------------------------------------------------------------------
@@ -2537,16 +2593,16 @@ int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s)
         if (atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
     switch (a.slices) {
-    case 1: return launch_fir_spectrum_t<1>(p, a, blocks, s);
-    case 2: return launch_fir_spectrum_t<2>(p, a, blocks, s);
-    case 3: return launch_fir_spectrum_t<3>(p, a, blocks, s);
-    case 4: return launch_fir_spectrum_t<4>(p, a, blocks, s);
-    case 5: return launch_fir_spectrum_t<5>(p, a, blocks, s);
-    case 6: return launch_fir_spectrum_t<6>(p, a, blocks, s);
-    case 7: return launch_fir_spectrum_t<7>(p, a, blocks, s);
-    case 8: return launch_fir_spectrum_t<8>(p, a, blocks, s);
-    case 9: return launch_fir_spectrum_t<9>(p, a, blocks, s);
-    case 10: return launch_fir_spectrum_t<10>(p, a, blocks, s);
+    case 1: return launch_fir_spectrum_n<1>(p, a, blocks, s);
+    case 2: return launch_fir_spectrum_n<2>(p, a, blocks, s);
+    case 3: return launch_fir_spectrum_n<3>(p, a, blocks, s);
+    case 4: return launch_fir_spectrum_n<4>(p, a, blocks, s);
+    case 5: return launch_fir_spectrum_n<5>(p, a, blocks, s);
+    case 6: return launch_fir_spectrum_n<6>(p, a, blocks, s);
+    case 7: return launch_fir_spectrum_n<7>(p, a, blocks, s);
+    case 8: return launch_fir_spectrum_n<8>(p, a, blocks, s);
+    case 9: return launch_fir_spectrum_n<9>(p, a, blocks, s);
+    case 10: return launch_fir_spectrum_n<10>(p, a, blocks, s);
     }
     return fail(DSPMI_EINVAL, "fir_spectrum: no kernel of %d slices", a.slices);
 }

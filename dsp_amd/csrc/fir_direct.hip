@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void fir_half_kernel(const FirParams<float> p,
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     StoreSink sink(p);
-    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink);
+    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
 }
 
 }  // namespace

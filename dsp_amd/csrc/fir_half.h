@@ -105,6 +105,39 @@ __device__ __forceinline__ unsigned wave_max(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Source: where a tile's samples come from.  MemorySource: from the rows at p.x (the walker's
+// double-buffered prefetch).  ToneSource<MAXT>: the rows are never in memory -- they are the sum of
+// up to MAXT tones per channel (the generator of tonegen/tonegen.c:25-40), and a tile's window is
+// computed straight into the staging registers from tables a small kernel prepares per call
+// (spectrum.hip, tone_chain_*):
+//   lane_tab[chan][j][256][2] cos, sin of 4 t dw for lane t (dw = the tone's increment)
+//   tile_tab[chan][tile][j][12] p, q = the tone's value and its quadrature (amplitude included) at
+//                             the window's first position, from the exactly advanced running
+//                             angle; delta = the tile's exact increment minus dw (the rounded
+//                             additions of one binade advance by a fixed multiple of the angle's
+//                             unit, which differs from dw by up to half a unit); cos, sin of
+//                             1024 increments; a spare slot; cos, sin of 1, 2, 3 increments
+//   hard[chan][tile]          1: the window is not one run of fixed increments (an angle crosses
+//                             a power of two inside it, a decreasing angle, ...): its samples were
+//                             generated into the row at p.x by the stand-alone generator and are
+//                             loaded like any other row
+// Lane t holds window positions 4 t + 1024 it + e (e < 4): the tone's (p, q) pair is turned to
+// 4 t by the lane table, corrected to second order for the drift 4 t delta, stepped by 1024
+// positions between pieces, and the three neighbours of a group come from the tile's constants
+// of 1, 2, 3 increments: 2.5 double-precision multiply-adds per sample and tone.  The sum is rounded to f32
+// once, like the generator's own output.  hist_out receives the last nh-1 samples of every row.
+struct MemorySource {
+    static constexpr int kTones = 0;
+};
+template <int MAXT>
+struct ToneSource {
+    static constexpr int kTones = MAXT;
+    const double *lane_tab, *tile_tab;
+    const unsigned *hard;
+    float *hist_out;
+    size_t hist_out_stride;
+};
+
 // Sink: what becomes of the results.  begin_tile(channel, first output of the tile) is called
 // by every lane before a tile's first block, emit(q, res) with a lane's four consecutive results
 // of block q (outputs tile + 1024 wave + 256 q + 16 (lane & 15) + 4 (lane >> 4) .. +3), and, where
@@ -113,10 +146,11 @@ __device__ __forceinline__ unsigned wave_max(unsigned v)
 // compiler's waits for the staging registers count the operations issued after each load, and
 // one load or store under a branch makes it wait for nearly everything (see fir_split_kernel).
 // LDS behind half_lds_bytes(NS) belongs to the sink.
-template <int NS, class Sink>
+template <int NS, class Sink, class Source>
 __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const u32x4 *__restrict__ htab, float tap_unscale,
-                                               char *smem_raw, Sink &sink)
+                                               char *smem_raw, Sink &sink, const Source &src)
 {
+    constexpr int MAXT = Source::kTones;  // 0: samples from memory
     constexpr int P = 32 * NS - 16;          // window positions ahead of a block's first output
     constexpr int NSTAGE = kSplitTile + P;   // samples staged per tile (a multiple of 16)
     constexpr int NQ = NSTAGE / 4;           // ... in groups of four
@@ -151,13 +185,28 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         int xoff, hoff;              // byte offset of the window's first sample from those
         long tile_start;
         unsigned chan;
+        // tone source only
+        unsigned tile;               // index of the tile in its row
+        bool hard;                   // samples from memory (the generator's own output), not computed here
+        float *obase;                // where the row's last nh-1 samples go (the row's last tile only)
+        int obytes;
     };
     long described = 0;
     auto describe = [&]() {
         Unit d;
         const bool valid = described++ < nunits;  // a tile past this workgroup's last reads nothing
         d.chan = valid ? cur_chan : 0;
+        d.tile = valid ? cur_tile : 0;
         d.tile_start = (long)cur_tile * kSplitTile;
+        d.hard = true;
+        d.obase = nullptr;
+        d.obytes = 0;
+        if constexpr (MAXT > 0) {
+            d.hard = !valid || __builtin_amdgcn_readfirstlane((int)src.hard[(size_t)d.chan * p.tiles_per_chan + d.tile]) != 0;
+            const bool last = valid && src.hist_out && cur_tile + 1 == p.tiles_per_chan;
+            d.obase = last ? src.hist_out + (size_t)d.chan * src.hist_out_stride : nullptr;
+            d.obytes = last ? (int)(nh - 1) * 4 : 0;
+        }
         if (++cur_tile == p.tiles_per_chan) {
             cur_tile = 0;
             ++cur_chan;
@@ -165,7 +214,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         const long sbase = d.tile_start - P;          // the window is samples [sbase, sbase + NSTAGE)
         const long lo = sbase < 0 ? 0 : sbase;
         long n = min(nx, sbase + NSTAGE) - lo;
-        if (n < 0 || !valid) n = 0;
+        if (n < 0 || !valid || (MAXT > 0 && !d.hard)) n = 0;
         d.xbase = p.x + (size_t)d.chan * p.x_stride + lo;
         d.xbytes = (int)n * 4;
         d.xoff = (int)(sbase - lo) * 4;               // <= 0: an offset before the row is out of range
@@ -217,6 +266,78 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         m = wave_max(m);
         if (lane == 0) maxima[(tile_index & 1) * 4 + wave] = m;
     };
+    // Tone source: a tile's whole window into the staging registers.  Only the history (first
+    // tile of a row) and the rare hard tiles touch memory on the way in.
+    auto fill = [&](const Unit &d) {
+        if constexpr (MAXT > 0) {
+            {
+                const __amdgpu_buffer_rsrc_t hrsrc = descriptor(d.hbase, d.hbytes);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int ho = d.hoff + (int)t * 16 + 4 * e;
+                    hstage[e] = __builtin_amdgcn_raw_buffer_load_b32(hrsrc, ho < 0 ? 0x7ffffff0 : ho, 0, 0);
+                }
+            }
+            if (d.hard) {
+                const __amdgpu_buffer_rsrc_t xrsrc = descriptor(d.xbase, d.xbytes);
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const unsigned u = t + 256 * it;
+                    const int g = (int)(it < NIT - 1 || u < (unsigned)NQ ? u : (unsigned)NQ - 1) * 16;
+                    const int xo = d.xoff + g;
+                    stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo < 0 ? 0x7ffffff0 : xo, 0, 0));
+                }
+            } else {
+                const double *tt = src.tile_tab + ((size_t)d.chan * p.tiles_per_chan + d.tile) * (MAXT * 12);
+                const double *lt = src.lane_tab + ((size_t)d.chan * MAXT * 256 + t) * 2;
+                const double t4 = (double)(4 * t);
+                double tp[MAXT], tq[MAXT];
+#pragma unroll
+                for (int j = 0; j < MAXT; j++) {
+                    const double p0 = tt[12 * j], q0 = tt[12 * j + 1], dl = tt[12 * j + 2];
+                    const double cl = lt[512 * j], sl = lt[512 * j + 1];
+                    const double pl = fma(q0, sl, p0 * cl), ql = fma(-p0, sl, q0 * cl);  // turned by 4 t dw
+                    const double eps = t4 * dl;                                          // ... and by the drift, to second order
+                    const double hc = fma(-0.5 * eps, eps, 1.0);
+                    tp[j] = fma(eps, ql, pl * hc);
+                    tq[j] = fma(-eps, pl, ql * hc);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    double v[4];
+#pragma unroll
+                    for (int j = 0; j < MAXT; j++) {
+                        v[0] = j ? v[0] + tp[j] : tp[j];
+#pragma unroll
+                        for (int e = 1; e < 4; e++) {
+                            const double ce = tt[12 * j + 4 + 2 * e], se = tt[12 * j + 5 + 2 * e];
+                            v[e] = fma(tq[j], se, j ? fma(tp[j], ce, v[e]) : tp[j] * ce);
+                        }
+                        if (it + 1 < NIT) {
+                            const double cg = tt[12 * j + 3], sg = tt[12 * j + 4];
+                            const double pn = fma(tq[j], sg, tp[j] * cg);
+                            tq[j] = fma(-tp[j], sg, tq[j] * cg);
+                            tp[j] = pn;
+                        }
+                    }
+                    // positions before the row's first sample (first tile: the history's, or zeros)
+                    // and, in the last piece, past the window hold nothing
+                    const unsigned u = t + 256 * it;
+                    const bool live = (it > 0 || d.tile_start + 4 * (long)u >= P) && (it < NIT - 1 || u < (unsigned)NQ);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) stage[it][e] = live ? (float)v[e] : 0.f;
+                }
+            }
+            // the row's last nh-1 samples are the next call's history
+            const __amdgpu_buffer_rsrc_t orsrc = descriptor(d.obase, d.obytes);
+            const u32x4 tail = __builtin_bit_cast(u32x4, stage[NIT - 1]);
+            const int o0 = ((int)(4 * (t + 256 * (NIT - 1))) - NSTAGE) * 4 + d.obytes;
+            __builtin_amdgcn_raw_buffer_store_b32(tail[0], orsrc, o0 < 0 ? 0x7ffffff0 : o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(tail[1], orsrc, o0 + 4 < 0 ? 0x7ffffff0 : o0 + 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(tail[2], orsrc, o0 + 8 < 0 ? 0x7ffffff0 : o0 + 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(tail[3], orsrc, o0 + 12 < 0 ? 0x7ffffff0 : o0 + 12, 0, 0);
+        }
+    };
     // the tile's scale, a power of two that brings its largest sample into [2^14, 2^15) (kept
     // within 2^-100 .. 2^100), and the factor that takes a sum of scaled products back
     auto scales = [&](long tile_index, float &scale, float &unscale) {
@@ -235,8 +356,12 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
 
     // prologue: the first tile is split with nothing to overlap it, the second is on its way
     Unit cur = describe();
+    if constexpr (MAXT > 0) {
+        fill(cur);
+    } else {
 #pragma unroll
-    for (int it = 0; it < NIT; it++) load_piece(cur, it);
+        for (int it = 0; it < NIT; it++) load_piece(cur, it);
+    }
 #pragma unroll
     for (int s = 0; s < NS; s++)
 #pragma unroll
@@ -248,8 +373,12 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
 #pragma unroll
     for (int it = 0; it < NIT; it++) put_piece(lds, it, scale_nxt);
     Unit nxt = describe();
+    if constexpr (MAXT > 0) {
+        fill(nxt);
+    } else {
 #pragma unroll
-    for (int it = 0; it < NIT; it++) load_piece(nxt, it);
+        for (int it = 0; it < NIT; it++) load_piece(nxt, it);
+    }
     publish_max(1);
     __syncthreads();
 
@@ -300,12 +429,13 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
 #pragma unroll
             for (; piece < NIT && (piece <= step || step == NSTEP - 1); piece++) {
                 put_piece(wr_planes, piece, scale_nxt);
-                load_piece(nxt2, piece);
+                if constexpr (MAXT == 0) load_piece(nxt2, piece);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s == 0 && q > 0) store(q - 1);
         }
         store(3);
+        if constexpr (MAXT > 0) fill(nxt2);
         if (unit + 1 < nunits) publish_max(unit + 2);
         if (Sink::kTileHook || unit + 1 < nunits) __syncthreads();  // the other planes and the maxima are complete, and every wave has left these planes
         if constexpr (Sink::kTileHook) sink.end_tile();

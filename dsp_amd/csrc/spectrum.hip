@@ -13,6 +13,7 @@
 //    (advance) and steps cos / sin by rotation where the angles form an exact arithmetic
 //    sequence.
 #include "common.h"
+#include "fft_internal.h"
 
 #include <cstdint>
 #include <type_traits>
@@ -327,15 +328,29 @@ template <typename O, int MAXT, int STEPS, bool GROUPS>
 __global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned ntone,
                                                            const double *__restrict__ w, const double *__restrict__ dw,
                                                            const double *__restrict__ amp, const double *__restrict__ phi,
-                                                           int use_sin)
+                                                           int use_sin, const unsigned *__restrict__ tile_flags,
+                                                           unsigned tile_len, unsigned lead)
 {
     constexpr unsigned RANGE = 64 * STEPS;
     __shared__ double partial[GROUPS ? RANGE : 1];
     const unsigned lane = threadIdx.x;
-    const unsigned nrange = (n + RANGE - 1) / RANGE;
-    const unsigned chan = blockIdx.x / nrange;
-    const size_t first = (size_t)(blockIdx.x - chan * nrange) * RANGE;
-    const unsigned len = (unsigned)min((size_t)RANGE, (size_t)n - first);
+    unsigned chan, len;
+    size_t first;
+    if (tile_flags) {
+        // only the tiles flagged: samples [tile_len * tile - lead, tile_len * (tile + 1)) of the row,
+        // the window the fused FIR + spectrum kernel stages for that tile (tile_len + lead <= RANGE)
+        const unsigned ntile = n / tile_len;
+        if (!tile_flags[blockIdx.x]) return;
+        chan = blockIdx.x / ntile;
+        const size_t start = (size_t)(blockIdx.x - chan * ntile) * tile_len;
+        first = start >= lead ? start - lead : 0;
+        len = (unsigned)(start + tile_len - first);
+    } else {
+        const unsigned nrange = (n + RANGE - 1) / RANGE;
+        chan = blockIdx.x / nrange;
+        first = (size_t)(blockIdx.x - chan * nrange) * RANGE;
+        len = (unsigned)min((size_t)RANGE, (size_t)n - first);
+    }
     O *xrow = x + (size_t)chan * x_stride + first;
 
     for (unsigned j0 = 0; j0 < (GROUPS ? ntone : 1u); j0 += MAXT) {
@@ -451,7 +466,155 @@ __global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, si
     }
 }
 
+
+// ---- tables for the generator inside the fused FIR + spectrum kernel (layouts in fir_half.h) ----
+// Per (channel, tone slot): the lane table cos, sin (4 t dw), t < 256.  Idle slots hold zeros
+// (their p, q are zero as well).
+__global__ __launch_bounds__(256) void tone_chain_lane_kernel(double *__restrict__ lane_tab, const double *__restrict__ dw,
+                                                              unsigned ntone, int slots)
+{
+    const unsigned t = threadIdx.x;
+    const unsigned chan = blockIdx.x / slots, j = blockIdx.x - chan * slots;
+    const bool on = j < ntone;
+    const double d = on ? dw[(size_t)chan * ntone + j] : 0.0;
+    double *lt = lane_tab + ((size_t)blockIdx.x * 256 + t) * 2;
+    const double a = (double)(4 * t) * d;
+    lt[0] = on ? tone_cos(a) : 0.0;
+    lt[1] = on ? tone_sin(a) : 0.0;
+}
+
+// Per (channel, tile): every tone's value p and quadrature q at the window's first position
+// (4096 tile - lead; before the row in its first tile, where the pair is turned back from sample
+// 0), the increment's deviation from dw inside the tile, and cos, sin of 1024, 1, 2 and 3
+// increments; or the flag that sends the tile through the stand-alone generator.  A tile is computed in place when,
+// for every tone, the increment is positive (or zero) and the angle non-negative, and either
+// the angles stay below 64 (the rounded additions then follow a + k dw to 3e-11 over the window)
+// or every addition of the window stays on one binade's grid, where a_k = a + k step exactly.
+__global__ __launch_bounds__(64) void tone_chain_tile_kernel(double *__restrict__ tile_tab, unsigned *__restrict__ hard,
+                                                             unsigned ntile, unsigned nchan, unsigned ntone, int slots,
+                                                             unsigned lead, const double *__restrict__ w,
+                                                             const double *__restrict__ dw, const double *__restrict__ amp,
+                                                             const double *__restrict__ phi, int use_sin)
+{
+    const size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (id >= (size_t)nchan * ntile) return;
+    const unsigned chan = (unsigned)(id / ntile), tile = (unsigned)(id - (size_t)chan * ntile);
+    const unsigned long long start = (unsigned long long)tile * 4096;
+    const unsigned long long k0 = start >= lead ? start - lead : 0;   // first sample of the window that exists
+    const unsigned back = (unsigned)(k0 + lead - start);              // window positions before it
+    const unsigned long long nadd = start + 4095 - k0;                // additions performed inside the window
+    double *tt = tile_tab + id * (size_t)slots * 12;
+    bool is_hard = false;
+    for (int j = 0; j < slots; j++) {
+        double p = 0.0, q = 0.0, delta = 0.0, cg = 0.0, sg = 0.0, ce[3] = {0.0, 0.0, 0.0}, se[3] = {0.0, 0.0, 0.0};
+        if (j < (int)ntone && !is_hard) {
+            const size_t s = (size_t)chan * ntone + j;
+            const double d = dw[s], w0 = w[s];
+            double a = w0;
+            if (d == 0.0) {
+                if (!(fabs(w0) <= 1.7e308)) is_hard = true;
+            } else if (!(d > 0.0) || !(w0 >= 0.0) || !(w0 <= 1.7e308)) {
+                is_hard = true;
+            } else {
+                a = advance(w0, d, k0);
+                if (!(a + (double)(nadd + 1) * d < 64.0)) {
+                    double step;
+                    const unsigned long long run = fixed_run(a, d, step);
+                    if (run >= nadd) delta = step - d;  // both within a factor of two of each other: exact
+                    else is_hard = true;
+                    if (fabs(delta) * 4400.0 > 2e-3) is_hard = true;  // second-order drift correction good to 1.3e-9
+                }
+            }
+            if (!is_hard) {
+                const double inc = d + delta;
+                const double ang = use_sin ? a : a + phi[s];
+                const double s0 = tone_sin(ang), c0 = tone_cos(ang);
+                const double am = use_sin ? 1.0 : amp[s];
+                p = use_sin ? s0 : am * c0;
+                q = use_sin ? c0 : -am * s0;
+                if (back) {
+                    const double b = (double)back * inc;
+                    const double cb = tone_cos(b), sb = tone_sin(b);
+                    const double pb = fma(-q, sb, p * cb);
+                    q = fma(p, sb, q * cb);
+                    p = pb;
+                }
+                cg = tone_cos(1024.0 * inc);
+                sg = tone_sin(1024.0 * inc);
+                for (int e = 0; e < 3; e++) {
+                    ce[e] = tone_cos((double)(e + 1) * inc);
+                    se[e] = tone_sin((double)(e + 1) * inc);
+                }
+            }
+        }
+        tt[12 * j] = p;
+        tt[12 * j + 1] = q;
+        tt[12 * j + 2] = delta;
+        tt[12 * j + 3] = cg;
+        tt[12 * j + 4] = sg;
+        tt[12 * j + 5] = 0.0;
+        for (int e = 0; e < 3; e++) {
+            tt[12 * j + 6 + 2 * e] = ce[e];
+            tt[12 * j + 7 + 2 * e] = se[e];
+        }
+    }
+    hard[id] = is_hard ? 1u : 0u;
+}
+
 }  // namespace
+
+namespace dspmi {
+
+static size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+size_t tone_chain_work_bytes(unsigned nx, unsigned nchan, int slots)
+{
+    const size_t tiles = (size_t)nchan * (nx / 4096);
+    return up256((size_t)nchan * slots * 512 * sizeof(double)) + up256(tiles * slots * 12 * sizeof(double)) +
+           up256(tiles * sizeof(unsigned)) + up256((size_t)nchan * nx * sizeof(float));
+}
+
+ToneChainTables tone_chain_carve(void *work, unsigned nx, unsigned nchan, int slots)
+{
+    const size_t tiles = (size_t)nchan * (nx / 4096);
+    char *b = static_cast<char *>(work);
+    ToneChainTables t;
+    t.lane_tab = reinterpret_cast<double *>(b);
+    b += up256((size_t)nchan * slots * 512 * sizeof(double));
+    t.tile_tab = reinterpret_cast<double *>(b);
+    b += up256(tiles * slots * 12 * sizeof(double));
+    t.hard = reinterpret_cast<unsigned *>(b);
+    b += up256(tiles * sizeof(unsigned));
+    t.spill = reinterpret_cast<float *>(b);
+    return t;
+}
+
+int tone_chain_prepare(const ToneChainTables &tab, unsigned nx, unsigned nchan, unsigned ntone, int slots, unsigned lead,
+                       const double *w, const double *dw, const double *amp, const double *phi, int use_sin, hipStream_t s)
+{
+    const unsigned ntile = nx / 4096;
+    const size_t tiles = (size_t)nchan * ntile;
+    if (use_sin && (!amp || !phi)) amp = phi = dw;  // never read in the sine form
+    hipLaunchKernelGGL(tone_chain_lane_kernel, dim3(nchan * (unsigned)slots), dim3(256), 0, s, tab.lane_tab, dw, ntone, slots);
+    hipLaunchKernelGGL(tone_chain_tile_kernel, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, s, tab.tile_tab, tab.hard, ntile,
+                       nchan, ntone, slots, lead, w, dw, amp, phi, use_sin);
+    auto kern = ntone == 1 ? tonegen_range_kernel<float, 1, kToneSteps, false>
+              : ntone == 2 ? tonegen_range_kernel<float, 2, kToneSteps, false>
+                           : tonegen_range_kernel<float, 4, kToneSteps, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), 0, s, tab.spill, (size_t)nx, nx, ntone, w, dw, amp, phi, use_sin,
+                       static_cast<const unsigned *>(tab.hard), 4096u, lead);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int tone_chain_finish(double *w, const double *dw, unsigned n, unsigned nseq, hipStream_t s)
+{
+    hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+}  // namespace dspmi
 
 extern "C" {
 
@@ -521,7 +684,8 @@ int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned nton
               : ntone <= 4 ? tonegen_range_kernel<O, 4, kToneSteps, false>
               : ntone <= 8 ? tonegen_range_kernel<O, 8, kToneSteps, false>
                            : tonegen_range_kernel<O, 8, kToneStepsGrouped, true>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nrange * nchan)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp, phi, use_sin);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrange * nchan)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp, phi, use_sin,
+                       static_cast<const unsigned *>(nullptr), 0u, 0u);
     hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;

@@ -61,6 +61,9 @@ _SIGS = {
     "dspmi_ols_exec_f32": (C.c_int, [_vp, _vp, _sz, _vp, _sz, _u, _u, _vp, _sz, _vp]),
     "dspmi_fft_exec_r2c_spectrum": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_fir_spectrum_f32": (C.c_int, [_vp, _vp, _vp, _u, C.c_int, C.c_float, _vp, _sz, _u, _u, _vp, _sz, _vp]),
+    "dspmi_tone_fir_spectrum_work_bytes": (_sz, [_u, _u, _u]),
+    "dspmi_tone_fir_spectrum_f32": (C.c_int, [_vp, _vp, _vp, _u, C.c_int, C.c_float, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int,
+                                              _vp, _sz, _vp, _sz, _vp, _sz, _vp]),
     "dspmi_fft_exec_r2c_spectrum_s16x2": (C.c_int, [_vp, _vp, _vp, _sz, _u, C.c_int, C.c_float, _vp]),
     "dspmi_power_spectrum_f32": (C.c_int, [_vp, _vp, _u, _u, _sz, C.c_int, C.c_float, _vp]),
     "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
@@ -186,6 +189,38 @@ class FirPlan:
             hp, hs = hist.data_ptr(), hist.stride(0) if nchan > 1 else self.nh - 1
         _check(lib().dspmi_fir_spectrum_f32(self._h, fft._h, out.data_ptr(), nbin, mode, scale, x.data_ptr(),
                                             x.stride(0) if nchan > 1 else nx, nx, nchan, hp, hs, _stream()), "fir_spectrum")
+        return out
+
+    def tone_spectrum(self, fft, gen, nx, hist=None, hist_out=None, nbin=None, mode=0, scale=1.0, out=None, work=None):
+        """The next nx samples of every channel of the ToneGen `gen`, filtered, as normalised
+        magnitude spectra of 4096 samples each -- generator, filter and transform in one kernel,
+        no sample ever written to memory.  hist / hist_out: [nchan, nh-1], the samples before this
+        call (None: zeros) and the ones the next call continues from.  work: a uint8 CUDA tensor of
+        tone_spectrum_work_bytes() bytes (allocated when None).  Returns [nchan * nx / 4096, nbin]."""
+        import torch
+        assert not self.f64 and nx % fft.n == 0
+        nchan = gen.nchan
+        dev = gen.w.device
+        if nbin is None:
+            nbin = fft.n // 2 + 1
+        if out is None:
+            out = torch.empty((nchan * (nx // fft.n), nbin), dtype=torch.float32, device=dev)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() == nchan * (nx // fft.n) * nbin
+        need = lib().dspmi_tone_fir_spectrum_work_bytes(nx, nchan, gen.ntone)
+        if work is None:
+            work = torch.empty((max(need, 1),), dtype=torch.uint8, device=dev)
+        assert work.is_cuda and work.dtype == torch.uint8 and work.is_contiguous()
+        ptrs = []
+        for h in (hist, hist_out):
+            if h is None:
+                ptrs += [None, 0]
+            else:
+                assert h.is_cuda and h.dtype == torch.float32 and h.shape == (nchan, self.nh - 1) and h.stride(1) == 1
+                ptrs += [h.data_ptr(), h.stride(0) if nchan > 1 else self.nh - 1]
+        _check(lib().dspmi_tone_fir_spectrum_f32(self._h, fft._h, out.data_ptr(), nbin, mode, scale, nx, nchan, gen.ntone,
+                                                 gen.w.data_ptr(), gen.dw.data_ptr(), gen.amp.data_ptr(), gen.phi.data_ptr(),
+                                                 int(gen.use_sin), ptrs[0], ptrs[1], ptrs[2], ptrs[3], work.data_ptr(),
+                                                 work.numel(), _stream()), "tone_fir_spectrum")
         return out
 
     def exec_s16x2(self, frames, out=None):

@@ -286,6 +286,34 @@ int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned
                            float scale, const float *x, size_t x_stride, unsigned nx, unsigned nchan,
                            const float *hist, size_t hist_stride, void *stream);
 
+/* The whole chain tone generator -> filter -> spectrum in one pass (tonegen_read,
+ * tonegen/tonegen.c:25-40, feeding alsa/main.c:542-568): the same spectra as dspmi_tonegen_f32
+ * into a buffer x followed by dspmi_fir_spectrum_f32(fir, fft, ps, ..., x, ..., hist), but neither
+ * the generated nor the filtered samples reach memory -- a tile's window of samples is computed
+ * in double precision straight into the filter's staging registers and rounded to f32 once, as
+ * the generator's own output is.  The running angle at every tile's first sample is the exact
+ * result of the reference's rounded additions (as in dspmi_tonegen_f32); inside a tile a tone
+ * advances by the one fixed increment those additions perform there, applied as a rotation by
+ * dw and a second-order correction for the difference: the double-precision sums agree with the
+ * separately generated ones to ~1e-10 of the amplitudes, so the f32 samples are the same except
+ * where a sum sits on a rounding boundary; in the cosine form the rounding of angle + phase is
+ * not reproduced per sample (<= half a unit of the angle, ~1e-10 rad at 1e6).
+ * Tiles in which an angle crosses a power of two above 64, and rows whose angles or increments
+ * are negative, are generated by dspmi_tonegen_f32's kernel into the work space and read back.
+ *   ntone: 1..4 (DSPMI_ENOSYS beyond: generate, then call dspmi_fir_spectrum_f32);
+ *   w, dw, amp, phi, use_sin: as for dspmi_tonegen_f32; w is advanced by nx samples;
+ *   hist: the nh-1 samples before this call's first (NULL: zeros); hist_out (may be NULL): receives
+ *   the last nh-1 generated samples of every row, the next call's hist; the two must not overlap;
+ *   work: device scratch of dspmi_tone_fir_spectrum_work_bytes(nx, nchan, ntone) bytes, 256-byte
+ *   aligned (tables of a few MB, and room for the rows of the tiles generated separately);
+ *   everything else as for dspmi_fir_spectrum_f32. */
+size_t dspmi_tone_fir_spectrum_work_bytes(unsigned nx, unsigned nchan, unsigned ntone);
+int dspmi_tone_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode, float scale,
+                                unsigned nx, unsigned nchan, unsigned ntone, double *w, const double *dw,
+                                const double *amp, const double *phi, int use_sin, const float *hist,
+                                size_t hist_stride, float *hist_out, size_t hist_out_stride, void *work,
+                                size_t work_bytes, void *stream);
+
 /* Tone generator of tonegen/tonegen.c:25-40 on the device, one generator per channel:
  * x[c][i] = sum_j amp[c][j]*cos(w[c][j] + phi[c][j]), then w[c][j] += dw[c][j], evaluated in
  * double and stored as f32; w (device, [nchan][ntone] doubles) carries the running phases from

@@ -325,3 +325,125 @@ def test_fir_and_spectrum_refuses_what_it_cannot_run():
         fir.spectrum(dsp_amd.FftPlan(2048, "f32"), x)
     with pytest.raises(dsp_amd.DspmiError, match="whole frames"):
         fir.spectrum(fft, torch.zeros((2, 5000), device="cuda"), out=torch.zeros((2, 2049), device="cuda"))
+
+
+def nearly_same_samples(a, b, scale):
+    """Samples computed in the fused kernel against the generator's own: the double sums agree to
+    ~1e-10 of the amplitudes, so the f32 values are the same except where a sum sits that close to
+    a rounding boundary (one unit in the last place apart) or to zero."""
+    d = (a.double() - b.double()).abs()
+    return bool(d.max() <= 1.3e-7 * scale) and float((d > 1e-9 * scale).double().mean()) <= 2e-3
+
+
+def _chain_two_calls(gen, fir, fft, n, hist, mode=0, nbin=None):
+    x = gen.read(n)
+    ps = fir.spectrum(fft, x, hist=hist, mode=mode, nbin=nbin)
+    return ps, x[:, n - (fir.nh - 1):].contiguous(), x
+
+
+@pytest.mark.parametrize("nh,ntone,use_sin", [(16, 2, True), (127, 2, True), (127, 1, False), (33, 3, False),
+                                              (305, 4, False), (2, 2, True), (200, 2, False)])
+def test_generator_filter_and_spectrum_in_one_kernel(nh, ntone, use_sin):
+    """dspmi_tone_fir_spectrum_f32 against the calls it replaces (dspmi_tonegen_f32, then
+    dspmi_fir_spectrum_f32), streamed in chunks with the history handed from call to call: same
+    running angles bit for bit, the carried samples the generator's own (a sample whose double sum
+    sits on a rounding boundary may differ by one unit in the last place), spectra within 1e-6, and
+    every spectrum within 1e-5 of the oracle's chain run in double.  Rows start from angle zero, so
+    the first tiles cross the powers of two above 2^13 (tiles the kernel reads from the stand-alone
+    generator's output) and the later ones run on the tables alone."""
+    fs, nchan, nfft = 48000.0, 6, 4096
+    rng = np.random.default_rng(nh * 10 + ntone)
+    freqs = np.array([[100.0 * (c + 1), 12000.0, 5321.7, 17.3][:ntone] for c in range(nchan)])
+    amps = rng.uniform(0.2, 2.0, (nchan, ntone))
+    phis = rng.uniform(-3.0, 3.0, (nchan, ntone))
+    phis[:, 0] = 0.0
+    taps = (oracle.TAPS16 if nh == 16 else oracle.windowed_sinc_taps(nh)).astype(np.float32)
+    mk = lambda: dsp_amd.ToneGen(fs, freqs, None if use_sin else amps, None if use_sin else phis, use_sin=use_sin)
+    g_one, g_two = mk(), mk()
+    fir, fft = dsp_amd.FirPlan(taps, "f32"), dsp_amd.FftPlan(nfft, "f32")
+    hist_a = torch.zeros((nchan, nh - 1), dtype=torch.float32, device="cuda")
+    hist_b = torch.empty_like(hist_a)
+    hist_two = hist_a.clone()
+    scale = float(ntone if use_sin else amps.sum(axis=1).max())
+    spectra, signal = [], []
+    for i, frames in enumerate((8, 1, 3)):
+        n = frames * nfft
+        first = i == 0
+        got = fir.tone_spectrum(fft, g_one, n, hist=None if first else hist_a, hist_out=hist_b)
+        want, hist_two, x = _chain_two_calls(g_two, fir, fft, n, None if first else hist_two)
+        assert torch.equal(g_one.w, g_two.w)
+        if nh > 1:
+            assert nearly_same_samples(hist_b, hist_two, scale), (i, (hist_b - hist_two).abs().max())
+        g, w_ = got.cpu().numpy(), want.cpu().numpy()
+        for f in range(g.shape[0]):
+            assert rel_l2(g[f], w_[f]) <= 1e-6, (i, f, rel_l2(g[f], w_[f]))
+        spectra.append(g.reshape(nchan, frames, -1))
+        signal.append(x.cpu().numpy())
+        hist_a, hist_b = hist_b, hist_a
+    # end to end against the oracle: its generator (double), its FIR on the f32 samples, its transform
+    got_ps = np.concatenate(spectra, axis=1)
+    total = got_ps.shape[1] * nfft
+    for c in (0, nchan - 1):
+        if use_sin:
+            tone = oracle.sin_tonegen(list(freqs[c]), fs, total)
+        else:
+            t = oracle.Tonegen()
+            for j in range(ntone):
+                t.add(fs, freqs[c, j], amps[c, j], phis[c, j])
+            tone = t.read(total)
+        want_y = oracle.fir_batch_f32(tone.astype(np.float32), taps, total)[0]
+        for f in range(got_ps.shape[1]):
+            want = oracle.power_spectrum(oracle.fft_r2c(want_y[f * nfft:(f + 1) * nfft]))
+            assert rel_l2(got_ps[c, f], want) <= 1e-5, (c, f)
+
+
+def test_generator_in_the_kernel_at_large_angles_and_odd_increments():
+    """Angles far along a stream (1e5 ... 3e8 rad: the exact increment of a tile differs from dw by
+    up to half a unit of the angle, which the kernel applies as a drift), an angle about to cross a
+    power of two, a tone that stands still (dw = 0), decreasing angles and negative starts (no
+    tables: those rows come from the stand-alone generator), and the spectrum modes."""
+    nchan, ntone, nfft, nh = 8, 2, 4096, 63
+    rng = np.random.default_rng(5)
+    dw = rng.uniform(0.01, 3.1, (nchan, ntone))
+    dw[:, 0] = rng.uniform(0.01, 0.6, nchan)   # one tone in the pass band: the errors are then relative to a signal, not to a residue
+    w0 = 10.0 ** rng.uniform(5, 8.5, (nchan, ntone))
+    w0[1, 0] = 2.0 ** 24 - 1000.0       # crosses 2^24 in the first tile
+    dw[2, 1] = 0.0
+    w0[2, 1] = 0.7
+    dw[3, 0] = -0.3                      # decreasing
+    w0[4, 1] = -5.0                      # negative start
+    taps = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    fir, fft = dsp_amd.FirPlan(taps, "f32"), dsp_amd.FftPlan(nfft, "f32")
+    gens = []
+    for _ in range(2):
+        g = dsp_amd.ToneGen(48000.0, np.ones((nchan, ntone)), use_sin=True)
+        g.dw.copy_(torch.from_numpy(dw).cuda())
+        g.w.copy_(torch.from_numpy(w0).cuda())
+        gens.append(g)
+    hist = torch.from_numpy(rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)).cuda()
+    hout = torch.empty_like(hist)
+    for mode, nbin, frames in ((0, 2049, 5), (1, 2048, 2), (2, 2049, 1)):
+        n = frames * nfft
+        got = fir.tone_spectrum(fft, gens[0], n, hist=hist, hist_out=hout, mode=mode, nbin=nbin, scale=4096.0)
+        x = gens[1].read(n)
+        want = fir.spectrum(fft, x, hist=hist, mode=mode, nbin=nbin, scale=4096.0)
+        assert torch.equal(gens[0].w, gens[1].w)
+        assert nearly_same_samples(hout, x[:, n - (nh - 1):], 2.0)
+        g, w_ = got.cpu().numpy(), want.cpu().numpy()
+        for f in range(g.shape[0]):
+            assert rel_l2(g[f], w_[f]) <= 1e-6, (mode, f, rel_l2(g[f], w_[f]))
+        hist = hout.clone()
+
+
+def test_generator_in_the_kernel_refuses_what_it_cannot_run():
+    fir, fft = dsp_amd.FirPlan(oracle.TAPS16.astype(np.float32), "f32"), dsp_amd.FftPlan(4096, "f32")
+    with pytest.raises(dsp_amd.DspmiError):
+        fir.tone_spectrum(fft, dsp_amd.ToneGen(48000.0, np.ones((2, 5))), 4096)                       # five tones
+    gen = dsp_amd.ToneGen(48000.0, np.ones((2, 2)))
+    with pytest.raises(dsp_amd.DspmiError):
+        fir.tone_spectrum(fft, gen, 4096, work=torch.empty((1024,), dtype=torch.uint8, device="cuda"))  # work space too small
+    h = torch.zeros((2, 15), dtype=torch.float32, device="cuda")
+    with pytest.raises(dsp_amd.DspmiError):
+        fir.tone_spectrum(fft, gen, 4096, hist=h, hist_out=h)                                         # history in place
+    with pytest.raises(dsp_amd.DspmiError):
+        fir.tone_spectrum(dsp_amd.FftPlan(2048, "f32"), gen, 4096)
