@@ -90,6 +90,10 @@ struct FirSpectrumLaunch {
     const unsigned *hard;
     float *hist_out;
     size_t hist_out_stride;
+    // the generators' running angles w[nseq], advanced by nx increments dw[nseq] by the same launch
+    double *w;
+    const double *dw;
+    unsigned nseq;
 };
 int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s);
 
@@ -108,7 +112,5 @@ size_t tone_chain_work_bytes(unsigned nx, unsigned nchan, int slots);
 ToneChainTables tone_chain_carve(void *work, unsigned nx, unsigned nchan, int slots);
 int tone_chain_prepare(const ToneChainTables &tab, unsigned nx, unsigned nchan, unsigned ntone, int slots, unsigned lead,
                        const double *w, const double *dw, const double *amp, const double *phi, int use_sin, hipStream_t s);
-// w[i] <- the running angle after n more samples
-int tone_chain_finish(double *w, const double *dw, unsigned n, unsigned nseq, hipStream_t s);
 
 }  // namespace dspmi

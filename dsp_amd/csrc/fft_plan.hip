@@ -1030,8 +1030,10 @@ int dspmi_tone_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, uns
     a.hard = tab.hard;
     a.hist_out = hist_out;
     a.hist_out_stride = hist_out_stride;
-    if (int rc = dspmi::fir_spectrum_launch(a, s)) return rc;
-    return dspmi::tone_chain_finish(w, dw, nx, nchan * ntone, s);
+    a.w = w;
+    a.dw = dw;
+    a.nseq = nchan * ntone;
+    return dspmi::fir_spectrum_launch(a, s);
 }
 
 int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float *ps, size_t batch, unsigned nbin, int mode,

@@ -29,6 +29,7 @@
 #include "common.h"
 #include "fft_internal.h"
 #include "fir_half.h"
+#include "tone_math.h"
 
 #include <cmath>
 #include <cstdint>
@@ -799,6 +800,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
 template <int NS>
 struct SpectrumSink {
     static constexpr bool kTileHook = true;
+    static constexpr bool kUnscaled = true;  // emit() takes the sums as they leave the matrix unit; the tile's factor goes into the spectrum's gain
     static constexpr int N = 2048, NT = 256, R0 = 8, R1 = 8, R2 = 8, R3 = 4, TW = 3, P = N / NT;
     C<float> *img;                    // the frame image, padded_len(N) complex
     const C<float> *tw1, *tw2, *tw3;  // LDS twiddle tables
@@ -809,10 +811,30 @@ struct SpectrumSink {
     int mode;
     float scale;
     size_t frame;
+    float tile_unscale;               // what the tile's results still have to be multiplied by (applied to the spectrum)
+    // A lane meets the same twiddles in every tile: those of the two long passes stay in registers
+    // for the whole launch (pass 3: W^(4 k r), k = lane mod 64, r = 1..7; pass 4: W^(j r), j = lane
+    // and lane + 256, r = 1..3) where the 26 registers do not cost a workgroup per CU; longer
+    // filters, whose tap images fill the registers, form them per tile as powers of one table product.
+    static constexpr bool kResident = NS <= 5;
+    C<float> rot3[kResident ? 7 : 1], rot4[2][kResident ? 3 : 1];
 
-    __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start)
+    __device__ __forceinline__ void load_twiddles()
+    {
+        if constexpr (!kResident) return;
+        const unsigned tl = threadIdx.x;
+#pragma unroll
+        for (int r = 1; r < 8; r++) rot3[r - 1] = tw[(4 * (tl & 63) * r) & (N - 1)];
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 1; r < 4; r++) rot4[b][r - 1] = tw[((tl + 256 * b) * r) & (N - 1)];
+    }
+
+    __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start, float unscale)
     {
         frame = (size_t)chan * frames_per_chan + (size_t)(tile_start / kSplitTile);
+        tile_unscale = unscale;
     }
     // four consecutive real results = two consecutive complex points of the packed frame
     __device__ __forceinline__ void emit(int q, f32x4 res)
@@ -837,7 +859,6 @@ struct SpectrumSink {
         const unsigned j2 = ((tl >> 3) << 6) + (tl & 7), w2 = j2 + (j2 >> 4);
         const unsigned j3 = ((tl >> 6) << 9) + (tl & 63), w3 = j3 + (j3 >> 4);
         const unsigned pb = (256 - tl) + ((256 - tl) >> 4);       // pad(256 - tl)
-        const C<float> *ta = tw2, *tb = tw2 + N / 64;              // W^(64 a), W^b
         C<float> v[P];
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = img[rb + 272 * r];    // points tl + 256 r
@@ -867,7 +888,11 @@ struct SpectrumSink {
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = img[rb + 272 * r];
         __syncthreads();
-        {
+        if constexpr (kResident) {
+#pragma unroll
+            for (int r = 1; r < 8; r++) v[r] = cmul(v[r], rot3[r - 1]);
+        } else {
+            const C<float> *ta = tw2, *tb = tw2 + N / 64;          // W^(64 a), W^b
             const unsigned e = 4 * (tl & 63);
             const C<float> p1 = cmul(ta[e >> 6], tb[e & 63]);
             const C<float> p2 = cmul(p1, p1), p3 = cmul(p2, p1), p4 = cmul(p2, p2);
@@ -892,12 +917,18 @@ struct SpectrumSink {
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < 2; b++) {
-            const unsigned e = tl + 256 * b;
-            const C<float> p1 = cmul(ta[e >> 6], tb[e & 63]);
-            const C<float> p2 = cmul(p1, p1);
-            v[4 * b + 1] = cmul(v[4 * b + 1], p1);
-            v[4 * b + 2] = cmul(v[4 * b + 2], p2);
-            v[4 * b + 3] = cmul(v[4 * b + 3], cmul(p2, p1));
+            if constexpr (kResident) {
+#pragma unroll
+                for (int r = 1; r < 4; r++) v[4 * b + r] = cmul(v[4 * b + r], rot4[b][r - 1]);
+            } else {
+                const C<float> *ta = tw2, *tb = tw2 + N / 64;
+                const unsigned e = tl + 256 * b;
+                const C<float> p1 = cmul(ta[e >> 6], tb[e & 63]);
+                const C<float> p2 = cmul(p1, p1);
+                v[4 * b + 1] = cmul(v[4 * b + 1], p1);
+                v[4 * b + 2] = cmul(v[4 * b + 2], p2);
+                v[4 * b + 3] = cmul(v[4 * b + 3], cmul(p2, p1));
+            }
             dft_reg<4, 1>(&v[4 * b]);
         }
         // park Z in natural order; Z[0] once more in the spare slot, where bin 0 looks for Z[N]
@@ -917,8 +948,9 @@ struct SpectrumSink {
             const unsigned k = tl + NT * i;
             const C<float> a = img[rb + 272 * i];
             const C<float> b0 = img[pb + 1904 - 272 * i];         // pad(N - k); the spare slot for k = 0
-            const C<float> e = {(a.re + b0.re) * 0.5f, (a.im - b0.im) * 0.5f};
-            const C<float> d = {(a.re - b0.re) * 0.5f, (a.im + b0.im) * 0.5f};
+            // twice E and twice D: the halving, like the tile's scale, goes into the gain below
+            const C<float> e = {a.re + b0.re, a.im - b0.im};
+            const C<float> d = {a.re - b0.re, a.im + b0.im};
             const C<float> o = {d.im, -d.re};
             const C<float> wo = cmul(tw2n[k], o);
             const C<float> xlo = {e.re + wo.re, e.im + wo.im}, xhi = {e.re - wo.re, wo.im - e.im};
@@ -928,7 +960,7 @@ struct SpectrumSink {
             part += mlo[i] + ((i == 0 && tl == 0 && nbin <= N) ? 0.f : mhi[i]);
         }
         const C<float> zmid = img[pad(N / 2)];
-        const float mmid = __builtin_amdgcn_sqrtf(zmid.re * zmid.re + zmid.im * zmid.im);
+        const float mmid = 2.f * __builtin_amdgcn_sqrtf(zmid.re * zmid.re + zmid.im * zmid.im);
         if (tl == 0) part += mmid;
         float div = 1.f, mul = 1.f;
         if (mode == 2) {
@@ -937,9 +969,11 @@ struct SpectrumSink {
         }
         // the two barriers of the sum also keep the next tile's results out of the image until
         // every lane has read its bins
-        const float sum = frame_sum<NT>(part, scratch, 0, tl);
+        // magnitudes so far: 2 / tile_unscale times the true ones
+        const float back = 0.5f * tile_unscale;
+        const float sum = frame_sum<NT>(part, scratch, 0, tl) * back;
         if (mode == 1 || (mode == 0 && sum > 0.00001f)) div = sum;
-        const float gain = mul * __builtin_amdgcn_rcpf(div);
+        const float gain = mul * back * __builtin_amdgcn_rcpf(div);
         const __amdgpu_buffer_rsrc_t dst = uniform_descriptor(ps + frame * nbin, (int)nbin * 4);
 #pragma unroll
         for (int i = 0; i < H; i++) {
@@ -977,6 +1011,7 @@ __global__ __launch_bounds__(256) void fir_spectrum_kernel(const FirParams<float
     sink.mode = mode;
     sink.scale = scale;
     sink.frame = 0;
+    sink.load_twiddles();
     fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
 }
 
@@ -988,8 +1023,22 @@ template <int NS, int MAXT>
 __global__ __launch_bounds__(256) void tone_fir_spectrum_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab,
                                                                 float tap_unscale, const C<float> *__restrict__ tw,
                                                                 const C<float> *__restrict__ tw2n, float *ps, unsigned nbin,
-                                                                int mode, float scale, const ToneSource<MAXT> src)
+                                                                int mode, float scale, const double *__restrict__ lane_tab,
+                                                                const double *__restrict__ tile_tab,
+                                                                const unsigned *__restrict__ hard, float *__restrict__ hist_out,
+                                                                size_t hist_out_stride, double *__restrict__ w,
+                                                                const double *__restrict__ dw, unsigned nseq)
 {
+    ToneSource<MAXT> src;
+    src.lane_tab = lane_tab;
+    src.tile_tab = tile_tab;
+    src.hard = hard;
+    src.hist_out = hist_out;
+    src.hist_out_stride = hist_out_stride;
+    // The tables were made from the running angles by the launch before this one, and nothing
+    // here reads them: they move on by the row length now, every addition rounded as the
+    // reference rounds it.
+    for (unsigned s = blockIdx.x * 256 + threadIdx.x; s < nseq; s += gridDim.x * 256) w[s] = advance(w[s], dw[s], p.nx);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr size_t kPlanes = half_lds_bytes(NS);
     SpectrumSink<NS> sink;
@@ -1005,6 +1054,7 @@ __global__ __launch_bounds__(256) void tone_fir_spectrum_kernel(const FirParams<
     sink.mode = mode;
     sink.scale = scale;
     sink.frame = 0;
+    sink.load_twiddles();
     fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink, src);
 }
 
@@ -1027,15 +1077,9 @@ int launch_fir_spectrum_t(const FirParams<float> &p, const dspmi::FirSpectrumLau
             DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr.mark();
         }
-        ToneSource<MAXT> src;
-        src.lane_tab = a.lane_tab;
-        src.tile_tab = a.tile_tab;
-        src.hard = a.hard;
-        src.hist_out = a.hist_out;
-        src.hist_out_stride = a.hist_out_stride;
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), fir_spectrum_lds_bytes(NS), s, p, static_cast<const u32x4 *>(a.tap_images),
                            a.tap_unscale, static_cast<const C<float> *>(a.tw_half), static_cast<const C<float> *>(a.tw_full), a.ps,
-                           a.nbin, a.mode, a.scale, src);
+                           a.nbin, a.mode, a.scale, a.lane_tab, a.tile_tab, a.hard, a.hist_out, a.hist_out_stride, a.w, a.dw, a.nseq);
     }
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;

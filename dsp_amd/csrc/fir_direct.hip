@@ -741,10 +741,11 @@ __global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p
 // needs no branch, and only 4-byte alignment.
 struct StoreSink {
     static constexpr bool kTileHook = false;
+    static constexpr bool kUnscaled = false;
     const FirParams<float> &p;
     __amdgpu_buffer_rsrc_t yrsrc;
     __device__ __forceinline__ explicit StoreSink(const FirParams<float> &params) : p(params) {}
-    __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start)
+    __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start, float)
     {
         const long left = (long)p.nxx - tile_start;
         yrsrc = uniform_descriptor(p.y + (size_t)chan * p.y_stride + tile_start, (int)(left < kSplitTile ? left : kSplitTile) * 4);

@@ -138,8 +138,10 @@ struct ToneSource {
     size_t hist_out_stride;
 };
 
-// Sink: what becomes of the results.  begin_tile(channel, first output of the tile) is called
-// by every lane before a tile's first block, emit(q, res) with a lane's four consecutive results
+// Sink: what becomes of the results.  begin_tile(channel, first output of the tile, the factor
+// that undoes the tile's and the taps' scales) is called by every lane before a tile's first
+// block, emit(q, res) with a lane's four consecutive results (already multiplied by that factor
+// unless Sink::kUnscaled)
 // of block q (outputs tile + 1024 wave + 256 q + 16 (lane & 15) + 4 (lane >> 4) .. +3), and, where
 // Sink::kTileHook is set, end_tile() after a workgroup barrier that follows the tile's last emit
 // (the hook may use barriers itself).  Memory instructions in a sink must be unconditional: the
@@ -392,7 +394,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         unsigned short *wr_planes = lds + ((unit & 1) ^ 1) * (2 * NSTAGE);
         const Unit nxt2 = describe();
         scales(unit + 1, scale_nxt, unscale_nxt);
-        sink.begin_tile(cur.chan, cur.tile_start);
+        sink.begin_tile(cur.chan, cur.tile_start, unscale_cur);
         f16x8 xf[3][2];
         f32x4 big[4], small[4];
         const unsigned short *xp = rd_planes + b_base;
@@ -405,7 +407,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         auto store = [&](int q) {
             f32x4 res;
 #pragma unroll
-            for (int r = 0; r < 4; r++) res[r] = (big[q][r] + small[q][r]) * unscale_cur;
+            for (int r = 0; r < 4; r++) res[r] = Sink::kUnscaled ? big[q][r] + small[q][r] : (big[q][r] + small[q][r]) * unscale_cur;
             sink.emit(q, res);
         };
         rd(0);

@@ -14,6 +14,7 @@
 //    sequence.
 #include "common.h"
 #include "fft_internal.h"
+#include "tone_math.h"
 
 #include <cstdint>
 #include <type_traits>
@@ -32,44 +33,6 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-
-// sin / cos of a running angle.  The reference evaluates libm's sin/cos on the accumulated,
-// never-reduced angle (tonegen/tonegen.c:36-37; it reaches ~1e6 rad after a million samples),
-// where a generic device sin falls into its slow large-argument path.  Here the angle is
-// reduced by multiples of pi/2 with a three-constant Cody-Waite step (each fused step leaves a
-// multiple of 2^-52 below 2, so it is exact; what remains is the ~1e-16 of the constants), and one
-// minimax polynomial in t^2 -- its coefficients chosen by the quadrant's parity -- gives
-// sin(t) or cos(t) on [-pi/4, pi/4].  The value agrees with libm's to about an ulp of double,
-// far below the f32 (or 16-bit) sample it ends up in.
-template <bool COS>
-__device__ __forceinline__ double tone_trig(double w)
-{
-    const double two_over_pi = 0.63661977236758134308;
-    const double c1 = 1.57079632679489655800e+00;   // pi/2, leading 53 bits
-    const double c2 = 6.12323399573676603587e-17;   // next bits
-    const double c3 = -1.49738490485916983145e-33;  // and the next
-    const double k = rint(w * two_over_pi);
-    double t = fma(-k, c1, w);
-    t = fma(-k, c2, t);
-    t = fma(-k, c3, t);
-    int q = (int)(long long)k;
-    if (COS) q += 1;  // cos(w) = sin(w + pi/2)
-    const bool even = (q & 1) != 0;  // odd quadrant count: the even function (cosine) of t
-    const double z = t * t;
-    // sin(t) = t + t*z*S(z), cos(t) = 1 - z/2 + z*z*C(z)   (coefficients of fdlibm's kernels)
-    double p = even ? -1.13596475577881948265e-11 : 1.58969099521155010221e-10;
-    p = fma(p, z, even ? 2.08757232129817482790e-09 : -2.50507602534068634195e-08);
-    p = fma(p, z, even ? -2.75573143513906633035e-07 : 2.75573137070700676789e-06);
-    p = fma(p, z, even ? 2.48015872894767294178e-05 : -1.98412698298579493134e-04);
-    p = fma(p, z, even ? -1.38888888888741095749e-03 : 8.33333333332248946124e-03);
-    p = fma(p, z, even ? 4.16666666666666019037e-02 : -1.66666666666666324348e-01);
-    const double odd_val = fma(t * z, p, t);
-    const double even_val = fma(z * z, p, fma(-0.5, z, 1.0));
-    const double v = even ? even_val : odd_val;
-    return (q & 2) ? -v : v;
-}
-__device__ __forceinline__ double tone_sin(double w) { return tone_trig<false>(w); }
-__device__ __forceinline__ double tone_cos(double w) { return tone_trig<true>(w); }
 
 // mode 0: ps = |X| / sum if sum > 1e-5 else |X|      (fft/src/main.c:120-141)
 // mode 1: ps = |X| / sum                             (alsa/main.c:473-487)
@@ -235,69 +198,6 @@ __global__ __launch_bounds__(64) void tonegen_kernel(O *__restrict__ x, size_t x
         if (live && j < (int)ntone) w[(size_t)c * ntone + j] = wl[j];
 }
 
-// ---- the same generator, parallel in time ---------------------------------------------
-// The recurrence w = fl(w + dw) is sequential, but its rounding is regular: while w stays in one
-// binade [2^e, 2^(e+1)) it is a multiple M*u of that binade's unit u = 2^(e-52), and adding dw
-// then rounds to M + D with one fixed integer D (dw/u rounded to nearest; on an exact tie the
-// result is the even neighbour, which is again a fixed step once M is even).  So the additions
-// inside a binade collapse into one integer multiply-add, and only the additions that cross into
-// the next binade are performed for real.  advance() returns bit for bit what `steps` sequential
-// additions produce, in a number of iterations proportional to the binades crossed, and every
-// range of the signal can start from its own exactly known angle.
-// The run of additions that stays on one binade's grid: starting from a (>= 0) with increment
-// d (> 0), a_k = a + k*step exactly for every k <= n.  n == 0 means the next addition has to be
-// performed for real (it changes the binade, or starts from zero / a subnormal / an odd multiple
-// on an exact tie); step == 0 with n = all ones means the angle no longer moves.
-__device__ __forceinline__ unsigned long long fixed_run(double a, double d, double &step)
-{
-    constexpr unsigned long long kMant = (1ull << 52) - 1, kOne = 1ull << 52;
-    step = 0.0;
-    const unsigned long long id = (unsigned long long)__double_as_longlong(d);
-    const int ed = (int)(id >> 52);  // d > 0: sign bit clear
-    const unsigned long long md = ed ? ((id & kMant) | kOne) : (id & kMant);
-    const unsigned long long ia = (unsigned long long)__double_as_longlong(a);
-    const int ea = (int)(ia >> 52);
-    const int sh = ea - (ed ? ed : 1);  // d / u = md / 2^sh, u = the unit of a's binade
-    if (ea == 0 || ea == 0x7ff || sh <= 0) return 0;
-    if (sh >= 54) return ~0ull;  // d < u/2
-    const unsigned long long M = (ia & kMant) | kOne;
-    const unsigned long long q = md >> sh, r = md & ((1ull << sh) - 1), half = 1ull << (sh - 1);
-    unsigned long long D;
-    if (r > half) D = q + 1;
-    else if (r < half) D = q;
-    else if (M & 1) return 0;  // tie from an odd multiple: one real addition makes it even
-    else D = q + (q & 1);
-    if (D == 0) return ~0ull;
-    // additions whose exact sum stays below 2^(e+1) round on this binade's grid
-    const unsigned long long lim = (1ull << 53) - 1 - q;
-    if (M > lim) return 0;
-    step = ldexp((double)D, ea - 1075);  // D * u, exact
-    return (lim - M) / D + 1;
-}
-
-__device__ __forceinline__ double advance(double a, double d, unsigned long long steps)
-{
-    if (!(a >= 0.0) || !(d > 0.0)) {
-        // negative or NaN operands: no shortcut, walk the additions
-        for (; steps; steps--) a += d;
-        return a;
-    }
-    while (steps) {
-        double step;
-        unsigned long long n = fixed_run(a, d, step);
-        if (n == 0) {
-            a += d;
-            steps--;
-            continue;
-        }
-        if (step == 0.0) return a;
-        if (n > steps) n = steps;
-        a = fma((double)n, step, a);  // the exact value is representable (at most 2^53 units): no rounding
-        steps -= n;
-    }
-    return a;
-}
-
 // running angles after a call: one lane per (channel, tone)
 __global__ __launch_bounds__(64) void tonegen_finish_kernel(double *__restrict__ w, const double *__restrict__ dw, unsigned n,
                                                             unsigned nseq)
@@ -325,32 +225,12 @@ constexpr unsigned kToneStepsGrouped = 32;          // samples per lane when the
 // running sum waits in LDS between groups, in double, so every sample still adds its tones in
 // the reference's order (tonegen/tonegen.c:31-37) and rounds once.
 template <typename O, int MAXT, int STEPS, bool GROUPS>
-__global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned ntone,
-                                                           const double *__restrict__ w, const double *__restrict__ dw,
-                                                           const double *__restrict__ amp, const double *__restrict__ phi,
-                                                           int use_sin, const unsigned *__restrict__ tile_flags,
-                                                           unsigned tile_len, unsigned lead)
+__device__ __forceinline__ void tone_range(O *__restrict__ x, size_t x_stride, unsigned ntone, const double *__restrict__ w,
+                                           const double *__restrict__ dw, const double *__restrict__ amp,
+                                           const double *__restrict__ phi, int use_sin, unsigned chan, size_t first, unsigned len,
+                                           double *partial)
 {
-    constexpr unsigned RANGE = 64 * STEPS;
-    __shared__ double partial[GROUPS ? RANGE : 1];
-    const unsigned lane = threadIdx.x;
-    unsigned chan, len;
-    size_t first;
-    if (tile_flags) {
-        // only the tiles flagged: samples [tile_len * tile - lead, tile_len * (tile + 1)) of the row,
-        // the window the fused FIR + spectrum kernel stages for that tile (tile_len + lead <= RANGE)
-        const unsigned ntile = n / tile_len;
-        if (!tile_flags[blockIdx.x]) return;
-        chan = blockIdx.x / ntile;
-        const size_t start = (size_t)(blockIdx.x - chan * ntile) * tile_len;
-        first = start >= lead ? start - lead : 0;
-        len = (unsigned)(start + tile_len - first);
-    } else {
-        const unsigned nrange = (n + RANGE - 1) / RANGE;
-        chan = blockIdx.x / nrange;
-        first = (size_t)(blockIdx.x - chan * nrange) * RANGE;
-        len = (unsigned)min((size_t)RANGE, (size_t)n - first);
-    }
+    const unsigned lane = threadIdx.x & 63;
     O *xrow = x + (size_t)chan * x_stride + first;
 
     for (unsigned j0 = 0; j0 < (GROUPS ? ntone : 1u); j0 += MAXT) {
@@ -466,99 +346,135 @@ __global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, si
     }
 }
 
-
-// ---- tables for the generator inside the fused FIR + spectrum kernel (layouts in fir_half.h) ----
-// Per (channel, tone slot): the lane table cos, sin (4 t dw), t < 256.  Idle slots hold zeros
-// (their p, q are zero as well).
-__global__ __launch_bounds__(256) void tone_chain_lane_kernel(double *__restrict__ lane_tab, const double *__restrict__ dw,
-                                                              unsigned ntone, int slots)
+template <typename O, int MAXT, int STEPS, bool GROUPS>
+__global__ __launch_bounds__(64) void tonegen_range_kernel(O *__restrict__ x, size_t x_stride, unsigned n, unsigned ntone,
+                                                           const double *__restrict__ w, const double *__restrict__ dw,
+                                                           const double *__restrict__ amp, const double *__restrict__ phi,
+                                                           int use_sin)
 {
-    const unsigned t = threadIdx.x;
-    const unsigned chan = blockIdx.x / slots, j = blockIdx.x - chan * slots;
-    const bool on = j < ntone;
-    const double d = on ? dw[(size_t)chan * ntone + j] : 0.0;
-    double *lt = lane_tab + ((size_t)blockIdx.x * 256 + t) * 2;
-    const double a = (double)(4 * t) * d;
-    lt[0] = on ? tone_cos(a) : 0.0;
-    lt[1] = on ? tone_sin(a) : 0.0;
+    constexpr unsigned RANGE = 64 * STEPS;
+    __shared__ double partial[GROUPS ? RANGE : 1];
+    const unsigned nrange = (n + RANGE - 1) / RANGE;
+    const unsigned chan = blockIdx.x / nrange;
+    const size_t first = (size_t)(blockIdx.x - chan * nrange) * RANGE;
+    const unsigned len = (unsigned)min((size_t)RANGE, (size_t)n - first);
+    tone_range<O, MAXT, STEPS, GROUPS>(x, x_stride, ntone, w, dw, amp, phi, use_sin, chan, first, len, partial);
 }
 
-// Per (channel, tile): every tone's value p and quadrature q at the window's first position
-// (4096 tile - lead; before the row in its first tile, where the pair is turned back from sample
-// 0), the increment's deviation from dw inside the tile, and cos, sin of 1024, 1, 2 and 3
-// increments; or the flag that sends the tile through the stand-alone generator.  A tile is computed in place when,
-// for every tone, the increment is positive (or zero) and the angle non-negative, and either
-// the angles stay below 64 (the rounded additions then follow a + k dw to 3e-11 over the window)
-// or every addition of the window stays on one binade's grid, where a_k = a + k step exactly.
-__global__ __launch_bounds__(64) void tone_chain_tile_kernel(double *__restrict__ tile_tab, unsigned *__restrict__ hard,
-                                                             unsigned ntile, unsigned nchan, unsigned ntone, int slots,
-                                                             unsigned lead, const double *__restrict__ w,
-                                                             const double *__restrict__ dw, const double *__restrict__ amp,
-                                                             const double *__restrict__ phi, int use_sin)
+
+// ---- tables for the generator inside the fused FIR + spectrum kernel (layouts in fir_half.h) ----
+// One launch prepares everything the fused kernel's tone source reads.
+//
+// Blocks below 4 * nchan * slots: the lane tables cos, sin (4 t dw), t < 256, a quarter of one
+// (channel, tone slot) each.  Idle slots hold zeros (their p, q are zero as well).
+//
+// The other blocks, one lane per (channel, tile): every tone's value p and quadrature q at the
+// window's first position (4096 tile - lead; before the row in its first tile, where the pair is
+// turned back from sample 0), the increment's deviation from dw inside the tile, and cos, sin of
+// 1024, 1, 2 and 3 increments; or the flag that marks the tile as hard.  A tile is computed in
+// place when, for every tone, the increment is positive (or zero) and the angle non-negative,
+// and either the angles stay below 64 (the rounded additions then follow a + k dw to 3e-11 over
+// the window) or every addition of the window stays on one binade's grid, where a_k = a + k step
+// exactly.  The wave then generates the windows of its hard tiles into the spill rows with the
+// stand-alone generator's routine, all lanes on one tile at a time.
+template <int MAXT>
+__global__ __launch_bounds__(64) void tone_chain_tables_kernel(double *__restrict__ lane_tab, double *__restrict__ tile_tab,
+                                                               unsigned *__restrict__ hard, float *__restrict__ spill, unsigned nx,
+                                                               unsigned nchan, unsigned ntone, int slots, unsigned lead,
+                                                               const double *__restrict__ w, const double *__restrict__ dw,
+                                                               const double *__restrict__ amp, const double *__restrict__ phi,
+                                                               int use_sin)
 {
-    const size_t id = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (id >= (size_t)nchan * ntile) return;
-    const unsigned chan = (unsigned)(id / ntile), tile = (unsigned)(id - (size_t)chan * ntile);
-    const unsigned long long start = (unsigned long long)tile * 4096;
-    const unsigned long long k0 = start >= lead ? start - lead : 0;   // first sample of the window that exists
-    const unsigned back = (unsigned)(k0 + lead - start);              // window positions before it
-    const unsigned long long nadd = start + 4095 - k0;                // additions performed inside the window
-    double *tt = tile_tab + id * (size_t)slots * 12;
-    bool is_hard = false;
-    for (int j = 0; j < slots; j++) {
-        double p = 0.0, q = 0.0, delta = 0.0, cg = 0.0, sg = 0.0, ce[3] = {0.0, 0.0, 0.0}, se[3] = {0.0, 0.0, 0.0};
-        if (j < (int)ntone && !is_hard) {
-            const size_t s = (size_t)chan * ntone + j;
-            const double d = dw[s], w0 = w[s];
-            double a = w0;
-            if (d == 0.0) {
-                if (!(fabs(w0) <= 1.7e308)) is_hard = true;
-            } else if (!(d > 0.0) || !(w0 >= 0.0) || !(w0 <= 1.7e308)) {
-                is_hard = true;
-            } else {
-                a = advance(w0, d, k0);
-                if (!(a + (double)(nadd + 1) * d < 64.0)) {
-                    double step;
-                    const unsigned long long run = fixed_run(a, d, step);
-                    if (run >= nadd) delta = step - d;  // both within a factor of two of each other: exact
-                    else is_hard = true;
-                    if (fabs(delta) * 4400.0 > 2e-3) is_hard = true;  // second-order drift correction good to 1.3e-9
-                }
-            }
-            if (!is_hard) {
-                const double inc = d + delta;
-                const double ang = use_sin ? a : a + phi[s];
-                const double s0 = tone_sin(ang), c0 = tone_cos(ang);
-                const double am = use_sin ? 1.0 : amp[s];
-                p = use_sin ? s0 : am * c0;
-                q = use_sin ? c0 : -am * s0;
-                if (back) {
-                    const double b = (double)back * inc;
-                    const double cb = tone_cos(b), sb = tone_sin(b);
-                    const double pb = fma(-q, sb, p * cb);
-                    q = fma(p, sb, q * cb);
-                    p = pb;
-                }
-                cg = tone_cos(1024.0 * inc);
-                sg = tone_sin(1024.0 * inc);
-                for (int e = 0; e < 3; e++) {
-                    ce[e] = tone_cos((double)(e + 1) * inc);
-                    se[e] = tone_sin((double)(e + 1) * inc);
-                }
-            }
-        }
-        tt[12 * j] = p;
-        tt[12 * j + 1] = q;
-        tt[12 * j + 2] = delta;
-        tt[12 * j + 3] = cg;
-        tt[12 * j + 4] = sg;
-        tt[12 * j + 5] = 0.0;
-        for (int e = 0; e < 3; e++) {
-            tt[12 * j + 6 + 2 * e] = ce[e];
-            tt[12 * j + 7 + 2 * e] = se[e];
-        }
+    const unsigned lane = threadIdx.x;
+    const unsigned lane_blocks = nchan * (unsigned)slots * 4;
+    if (blockIdx.x < lane_blocks) {
+        const unsigned cs = blockIdx.x >> 2, t = (blockIdx.x & 3) * 64 + lane;
+        const unsigned chan = cs / slots, j = cs - chan * slots;
+        const bool on = j < ntone;
+        const double d = on ? dw[(size_t)chan * ntone + j] : 0.0;
+        double *lt = lane_tab + ((size_t)cs * 256 + t) * 2;
+        const double a = (double)(4 * t) * d;
+        lt[0] = on ? tone_cos(a) : 0.0;
+        lt[1] = on ? tone_sin(a) : 0.0;
+        return;
     }
-    hard[id] = is_hard ? 1u : 0u;
+    const unsigned ntile = nx / 4096;
+    const size_t base = (size_t)(blockIdx.x - lane_blocks) * 64;
+    const size_t id = base + lane;
+    bool is_hard = false;
+    if (id < (size_t)nchan * ntile) {
+        const unsigned chan = (unsigned)(id / ntile), tile = (unsigned)(id - (size_t)chan * ntile);
+        const unsigned long long start = (unsigned long long)tile * 4096;
+        const unsigned long long k0 = start >= lead ? start - lead : 0;   // first sample of the window that exists
+        const unsigned back = (unsigned)(k0 + lead - start);              // window positions before it
+        const unsigned long long nadd = start + 4095 - k0;                // additions performed inside the window
+        double *tt = tile_tab + id * (size_t)slots * 12;
+        for (int j = 0; j < slots; j++) {
+            double p = 0.0, q = 0.0, delta = 0.0, cg = 0.0, sg = 0.0, ce[3] = {0.0, 0.0, 0.0}, se[3] = {0.0, 0.0, 0.0};
+            if (j < (int)ntone && !is_hard) {
+                const size_t s = (size_t)chan * ntone + j;
+                const double d = dw[s], w0 = w[s];
+                double a = w0;
+                if (d == 0.0) {
+                    if (!(fabs(w0) <= 1.7e308)) is_hard = true;
+                } else if (!(d > 0.0) || !(w0 >= 0.0) || !(w0 <= 1.7e308)) {
+                    is_hard = true;
+                } else {
+                    a = advance(w0, d, k0);
+                    if (!(a + (double)(nadd + 1) * d < 64.0)) {
+                        double step;
+                        const unsigned long long run = fixed_run(a, d, step);
+                        if (run >= nadd) delta = step - d;  // both within a factor of two of each other: exact
+                        else is_hard = true;
+                        if (fabs(delta) * 4400.0 > 2e-3) is_hard = true;  // second-order drift correction good to 1.3e-9
+                    }
+                }
+                if (!is_hard) {
+                    const double inc = d + delta;
+                    const double ang = use_sin ? a : a + phi[s];
+                    const double s0 = tone_sin(ang), c0 = tone_cos(ang);
+                    const double am = use_sin ? 1.0 : amp[s];
+                    p = use_sin ? s0 : am * c0;
+                    q = use_sin ? c0 : -am * s0;
+                    if (back) {
+                        const double b = (double)back * inc;
+                        const double cb = tone_cos(b), sb = tone_sin(b);
+                        const double pb = fma(-q, sb, p * cb);
+                        q = fma(p, sb, q * cb);
+                        p = pb;
+                    }
+                    cg = tone_cos(1024.0 * inc);
+                    sg = tone_sin(1024.0 * inc);
+                    for (int e = 0; e < 3; e++) {
+                        ce[e] = tone_cos((double)(e + 1) * inc);
+                        se[e] = tone_sin((double)(e + 1) * inc);
+                    }
+                }
+            }
+            tt[12 * j] = p;
+            tt[12 * j + 1] = q;
+            tt[12 * j + 2] = delta;
+            tt[12 * j + 3] = cg;
+            tt[12 * j + 4] = sg;
+            tt[12 * j + 5] = 0.0;
+            for (int e = 0; e < 3; e++) {
+                tt[12 * j + 6 + 2 * e] = ce[e];
+                tt[12 * j + 7 + 2 * e] = se[e];
+            }
+        }
+        hard[id] = is_hard ? 1u : 0u;
+    }
+    unsigned long long todo = __ballot(is_hard);
+    while (todo) {
+        const int bit = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const size_t hid = base + (unsigned)bit;
+        const unsigned chan = (unsigned)(hid / ntile), tile = (unsigned)(hid - (size_t)chan * ntile);
+        const size_t start = (size_t)tile * 4096;
+        const size_t first = start >= lead ? start - lead : 0;
+        tone_range<float, MAXT, kToneSteps, false>(spill, nx, ntone, w, dw, amp, phi, use_sin, chan, first,
+                                                   (unsigned)(start + 4096 - first), nullptr);
+    }
 }
 
 }  // namespace
@@ -592,24 +508,13 @@ ToneChainTables tone_chain_carve(void *work, unsigned nx, unsigned nchan, int sl
 int tone_chain_prepare(const ToneChainTables &tab, unsigned nx, unsigned nchan, unsigned ntone, int slots, unsigned lead,
                        const double *w, const double *dw, const double *amp, const double *phi, int use_sin, hipStream_t s)
 {
-    const unsigned ntile = nx / 4096;
-    const size_t tiles = (size_t)nchan * ntile;
+    const size_t tiles = (size_t)nchan * (nx / 4096);
     if (use_sin && (!amp || !phi)) amp = phi = dw;  // never read in the sine form
-    hipLaunchKernelGGL(tone_chain_lane_kernel, dim3(nchan * (unsigned)slots), dim3(256), 0, s, tab.lane_tab, dw, ntone, slots);
-    hipLaunchKernelGGL(tone_chain_tile_kernel, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, s, tab.tile_tab, tab.hard, ntile,
-                       nchan, ntone, slots, lead, w, dw, amp, phi, use_sin);
-    auto kern = ntone == 1 ? tonegen_range_kernel<float, 1, kToneSteps, false>
-              : ntone == 2 ? tonegen_range_kernel<float, 2, kToneSteps, false>
-                           : tonegen_range_kernel<float, 4, kToneSteps, false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64), 0, s, tab.spill, (size_t)nx, nx, ntone, w, dw, amp, phi, use_sin,
-                       static_cast<const unsigned *>(tab.hard), 4096u, lead);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
-int tone_chain_finish(double *w, const double *dw, unsigned n, unsigned nseq, hipStream_t s)
-{
-    hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
+    const size_t blocks = (size_t)nchan * slots * 4 + (tiles + 63) / 64;
+    if (blocks > 0x7fffffffull) return fail(DSPMI_EINVAL, "tone_fir_spectrum: too many tiles for one launch");
+    auto kern = ntone == 1 ? tone_chain_tables_kernel<1> : ntone == 2 ? tone_chain_tables_kernel<2> : tone_chain_tables_kernel<4>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), 0, s, tab.lane_tab, tab.tile_tab, tab.hard, tab.spill, nx, nchan,
+                       ntone, slots, lead, w, dw, amp, phi, use_sin);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
@@ -684,8 +589,7 @@ int tonegen_run(O *x, size_t x_stride, unsigned n, unsigned nchan, unsigned nton
               : ntone <= 4 ? tonegen_range_kernel<O, 4, kToneSteps, false>
               : ntone <= 8 ? tonegen_range_kernel<O, 8, kToneSteps, false>
                            : tonegen_range_kernel<O, 8, kToneStepsGrouped, true>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nrange * nchan)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp, phi, use_sin,
-                       static_cast<const unsigned *>(nullptr), 0u, 0u);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nrange * nchan)), dim3(64), 0, s, x, x_stride, n, ntone, w, dw, amp, phi, use_sin);
     hipLaunchKernelGGL(tonegen_finish_kernel, dim3((nseq + 63) / 64), dim3(64), 0, s, w, dw, n, nseq);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
