@@ -62,8 +62,10 @@ struct PerDeviceOnce {
 };
 
 // The f16 matrix-pipe form of an f32 FIR plan's taps (fir_direct.hip): the register images, the
-// factor that undoes the taps' scale, the slice count.  Fails when the plan runs another kernel.
-int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *slices, unsigned *nh, int *device);
+// factor that undoes the taps' scale, the slice count, and the taps themselves (device, f32).
+// Fails when the plan holds no such images.
+int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *slices, unsigned *nh, int *device,
+                    const float **taps);
 
 }  // namespace dspmi
 

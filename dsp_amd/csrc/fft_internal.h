@@ -75,6 +75,7 @@ struct FirSpectrumLaunch {
     size_t x_stride, hist_stride;
     unsigned nx, nh, nchan;
     const void *tap_images;
+    const float *taps;   // the plan's taps as they are (nh floats)
     float tap_unscale;
     int slices;
     const void *tw_half, *tw_full;

@@ -939,7 +939,7 @@ int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned
     if (int rc = dspmi::check_device(fft->device, "fir_spectrum")) return rc;
     dspmi::FirSpectrumLaunch a{};
     int fir_device = -1;
-    if (int rc = dspmi::fir_half_images(fir, &a.tap_images, &a.tap_unscale, &a.slices, &a.nh, &fir_device)) return rc;
+    if (int rc = dspmi::fir_half_images(fir, &a.tap_images, &a.tap_unscale, &a.slices, &a.nh, &fir_device, &a.taps)) return rc;
     if (fir_device != fft->device) return dspmi::fail(DSPMI_EINVAL, "fir_spectrum: the two plans belong to different devices");
     if (fft->precision != DSPMI_F32 || fft->n != 4096 || !fused_real(fft))
         return dspmi::fail(DSPMI_ENOSYS, "fir_spectrum: needs an f32 transform plan of 4096 points");
@@ -983,7 +983,7 @@ int dspmi_tone_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, uns
     if (int rc = dspmi::check_device(fft->device, "tone_fir_spectrum")) return rc;
     dspmi::FirSpectrumLaunch a{};
     int fir_device = -1;
-    if (int rc = dspmi::fir_half_images(fir, &a.tap_images, &a.tap_unscale, &a.slices, &a.nh, &fir_device)) return rc;
+    if (int rc = dspmi::fir_half_images(fir, &a.tap_images, &a.tap_unscale, &a.slices, &a.nh, &fir_device, &a.taps)) return rc;
     if (fir_device != fft->device) return dspmi::fail(DSPMI_EINVAL, "tone_fir_spectrum: the two plans belong to different devices");
     if (fft->precision != DSPMI_F32 || fft->n != 4096 || !fused_real(fft))
         return dspmi::fail(DSPMI_ENOSYS, "tone_fir_spectrum: needs an f32 transform plan of 4096 points");

@@ -2622,6 +2622,7 @@ int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s)
     FirParams<float> p{};
     p.x = a.x;
     p.hist = a.hist;
+    p.taps = a.taps;
     p.x_stride = a.x_stride;
     p.hist_stride = a.hist_stride;
     p.nxx = p.nx = a.nx;

@@ -1286,9 +1286,10 @@ int launch(const FirParams<T> &p, unsigned nchan, hipStream_t stream)
 }
 
 template <typename T>
-int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precision)
+int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precision, unsigned opts = 0)
 {
     if (!out || !taps || nh == 0) return dspmi::fail(DSPMI_EINVAL, "fir_create: null argument or nh == 0");
+    if (opts & ~(DSPMI_FIR_FULL_RANGE | DSPMI_FIR_F32_PRODUCTS)) return dspmi::fail(DSPMI_EINVAL, "fir_create: unknown option bits %#x", opts);
     if (device < 0) DSPMI_HIP(hipGetDevice(&device));
     int prev = 0;
     DSPMI_HIP(hipGetDevice(&prev));
@@ -1314,7 +1315,11 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         // A/B knob: "valu", "mfma" (the f32 matrix kernel), "f16" / "bf16" (the two split kernels,
         // wherever they apply) or "ols" (overlap-save from kOlsMinTaps up) pin that path; anything
         // else is automatic
+        // (the creation options select the same paths from the API: DSPMI_FIR_F32_PRODUCTS = "mfma",
+        // DSPMI_FIR_FULL_RANGE = "bf16" where the f16 kernel would run)
         const char *env = getenv("DSPMI_FIR_VARIANT");
+        if (opts & DSPMI_FIR_F32_PRODUCTS) env = "mfma";
+        else if ((opts & DSPMI_FIR_FULL_RANGE) && !env && nh >= kSplitAutoMinTaps && nh <= 32 * kSplitMaxSlices - 15) env = "bf16";
         const bool valu = env && !strcmp(env, "valu"), mfma = env && !strcmp(env, "mfma");
         const bool want_bf16 = env && !strcmp(env, "bf16"), want_ols = env && !strcmp(env, "ols");
         const bool want_half = !want_bf16, want_split = want_bf16 || (env && !strcmp(env, "f16"));
@@ -1467,7 +1472,8 @@ int dspmi_fir_exec_f64_desc(dspmi_fir_t plan, double *y, size_t y_stride, unsign
 
 namespace dspmi {
 
-int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *slices, unsigned *nh, int *device)
+int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *slices, unsigned *nh, int *device,
+                    const float **taps)
 {
     if (!plan) return fail(DSPMI_EINVAL, "null FIR plan");
     if (!plan->half_tab)
@@ -1477,6 +1483,7 @@ int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *
     *slices = plan->split_ns;
     *nh = plan->nh;
     *device = plan->device;
+    *taps = static_cast<const float *>(plan->taps_dev);
     return DSPMI_OK;
 }
 
@@ -1487,6 +1494,11 @@ extern "C" {
 int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device)
 {
     return create<float>(plan, taps, nh, device, DSPMI_F32);
+}
+
+int dspmi_fir_create_f32_opts(dspmi_fir_t *plan, const float *taps, unsigned nh, int device, unsigned options)
+{
+    return create<float>(plan, taps, nh, device, DSPMI_F32, options);
 }
 
 int dspmi_fir_create_f64(dspmi_fir_t *plan, const double *taps, unsigned nh, int device)

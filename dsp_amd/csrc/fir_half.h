@@ -342,11 +342,13 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     };
     // the tile's scale, a power of two that brings its largest sample into [2^14, 2^15) (kept
     // within 2^-100 .. 2^100), and the factor that takes a sum of scaled products back
-    auto scales = [&](long tile_index, float &scale, float &unscale) {
+    auto scales = [&](long tile_index, float &scale, float &unscale, bool &nonfinite) {
         const u32x4 m4 = *reinterpret_cast<const u32x4 *>(maxima + (tile_index & 1) * 4);
         const unsigned m01 = m4[0] > m4[1] ? m4[0] : m4[1], m23 = m4[2] > m4[3] ? m4[2] : m4[3];
         const unsigned m = m01 > m23 ? m01 : m23;
-        int e = 268 - (int)((__builtin_amdgcn_readfirstlane((int)m) >> 23) & 0xff);
+        const int mu = __builtin_amdgcn_readfirstlane((int)m);
+        nonfinite = MAXT == 0 && (unsigned)mu >= 0x7f800000u;  // an infinity or a NaN somewhere in the window
+        int e = 268 - (int)((mu >> 23) & 0xff);
         e = e < 27 ? 27 : (e > 227 ? 227 : e);
         scale = __builtin_bit_cast(float, e << 23);
         unscale = __builtin_bit_cast(float, (254 - e) << 23) * tap_unscale;
@@ -371,7 +373,8 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     publish_max(0);
     __syncthreads();
     float scale_nxt, unscale_cur, unscale_nxt;
-    scales(0, scale_nxt, unscale_cur);
+    bool exact_cur, exact_nxt;
+    scales(0, scale_nxt, unscale_cur, exact_cur);
 #pragma unroll
     for (int it = 0; it < NIT; it++) put_piece(lds, it, scale_nxt);
     Unit nxt = describe();
@@ -393,8 +396,8 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         const unsigned short *rd_planes = lds + (unit & 1) * (2 * NSTAGE);
         unsigned short *wr_planes = lds + ((unit & 1) ^ 1) * (2 * NSTAGE);
         const Unit nxt2 = describe();
-        scales(unit + 1, scale_nxt, unscale_nxt);
-        sink.begin_tile(cur.chan, cur.tile_start, unscale_cur);
+        scales(unit + 1, scale_nxt, unscale_nxt, exact_nxt);
+        sink.begin_tile(cur.chan, cur.tile_start, exact_cur ? 1.f : unscale_cur);
         f16x8 xf[3][2];
         f32x4 big[4], small[4];
         const unsigned short *xp = rd_planes + b_base;
@@ -408,6 +411,31 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
             f32x4 res;
 #pragma unroll
             for (int r = 0; r < 4; r++) res[r] = Sink::kUnscaled ? big[q][r] + small[q][r] : (big[q][r] + small[q][r]) * unscale_cur;
+            if constexpr (MAXT == 0) {
+                // A window with an infinity or a NaN in it has no scale: its tile is summed tap by tap
+                // in f32 instead, as the reference sums (fft/src/main.c:197-203), so exactly the
+                // outputs whose nh samples include that one are not finite.  Rare, slow, and after
+                // it every earlier memory operation has landed.
+                if (exact_cur) {
+                    const long o0 = cur.tile_start + 1024 * (long)wave + 256 * q + 16 * (lane & 15) + 4 * (lane >> 4);
+                    const float *xr = p.x + (size_t)cur.chan * p.x_stride;
+                    const float *hr = p.hist ? p.hist + (size_t)cur.chan * p.hist_stride + (nh - 1) : nullptr;
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (long j = 0; j < nh; j++) {
+                        const float hj = p.taps[j];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const long k = o0 + r - j;
+                            float xv = 0.f;
+                            if (k >= 0 && k < nx) xv = xr[k];
+                            else if (k < 0 && hr) xv = hr[k];
+                            acc[r] = __builtin_fmaf(hj, xv, acc[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) res[r] = acc[r];
+                }
+            }
             sink.emit(q, res);
         };
         rd(0);
@@ -444,6 +472,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         cur = nxt;
         nxt = nxt2;
         unscale_cur = unscale_nxt;
+        exact_cur = exact_nxt;
     };
     iteration(0);  // a copy of the loop body, so that the loop is entered with its own order of memory operations
     for (long unit = 1; unit < nunits; unit++) iteration(unit);

@@ -41,6 +41,7 @@ _SIGS = {
     "dspmi_abi_version": (C.c_int, []),
     "dspmi_device_count": (C.c_int, []),
     "dspmi_fir_create_f32": (C.c_int, [C.POINTER(_vp), _fp, _u, C.c_int]),
+    "dspmi_fir_create_f32_opts": (C.c_int, [C.POINTER(_vp), _fp, _u, C.c_int, _u]),
     "dspmi_fir_create_f64": (C.c_int, [C.POINTER(_vp), _dp, _u, C.c_int]),
     "dspmi_fir_destroy": (C.c_int, [_vp]),
     "dspmi_fir_exec_f32": (C.c_int, [_vp, _vp, _sz, _u, _vp, _sz, _u, _u, _vp, _sz, _u, _vp]),
@@ -136,7 +137,9 @@ def _stream():
 class FirPlan:
     """Taps resident on the device; exec() runs the batched FIR on torch CUDA tensors."""
 
-    def __init__(self, taps, dtype="f32", device=-1):
+    FULL_RANGE, F32_PRODUCTS = 1, 2   # creation options of f32 plans (dspmi.h)
+
+    def __init__(self, taps, dtype="f32", device=-1, options=0):
         self.f64 = dtype in ("f64", np.float64)
         self.nh = len(taps)
         self._h = C.c_void_p()
@@ -145,7 +148,7 @@ class FirPlan:
             _check(lib().dspmi_fir_create_f64(C.byref(self._h), t.ctypes.data_as(_dp), self.nh, device), "fir_create_f64")
         else:
             t = np.ascontiguousarray(taps, dtype=np.float32)
-            _check(lib().dspmi_fir_create_f32(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, device), "fir_create_f32")
+            _check(lib().dspmi_fir_create_f32_opts(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, device, options), "fir_create_f32")
 
     @property
     def variant(self):

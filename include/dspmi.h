@@ -77,9 +77,13 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  *                   kernel otherwise; also up to 32 taps on rows of fewer than 2048 samples);
  *   up to 32 taps   f32 multiply-accumulate chains on the matrix unit;
  *   33 .. 305       the same sum through the f16 matrix pipe: samples and taps as two f16 parts
- *                   each, under one power-of-two scale per 4096-output tile, accumulated in f32.
- *                   A sample more than 2^39 below the largest of its tile is not carried, and a
- *                   non-finite sample makes its whole tile non-finite;
+ *                   each, under one power-of-two scale per 4096-output tile (the tile's window of
+ *                   4096 + up to 304 samples), accumulated in f32.  What that changes against f32
+ *                   products: a sample more than 2^39 below the largest of its tile is not carried --
+ *                   every output is within 2^-37 sqrt(nh) max|h| of its tile's largest sample, whatever
+ *                   the samples under its own taps.  A tile whose window holds an infinity or a NaN
+ *                   is summed tap by tap in f32 instead, so exactly the outputs the reference would
+ *                   make non-finite are (fft/src/main.c:197-203);
  *   306 .. 16384    overlap-save (the frequency-domain convolution doc/notes:81-82 names) when
  *                   flags == 0, nxx == nx and the rows hold enough work (up to 899 taps: two
  *                   transforms of four times the tap count; from 900 taps: nx * nh >= 4e5, in
@@ -88,6 +92,16 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  * DSPMI_FIR_VARIANT = mfma | f16 | bf16 | ols in the environment at creation pins the f32 kernel,
  * the f16 kernel, its three-part bf16 sibling (no scale, full f32 exponent range) or overlap-save. */
 int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device);
+/* The same with options:
+ *   DSPMI_FIR_FULL_RANGE    never the f16 kernel: 33 .. 305 taps run its sibling with three bf16 parts
+ *                           per operand and no scale -- products exact to 2^-24 over the whole f32
+ *                           exponent range, about 20 % slower at 127 taps;
+ *   DSPMI_FIR_F32_PRODUCTS  every tap count on the f32 matrix kernel: f32 products, f32 sums.
+ * In the two matrix kernels these options select, a non-finite sample makes the outputs of the
+ * 16-output blocks around its own nh non-finite as well (up to 15 before, up to 46 after). */
+#define DSPMI_FIR_FULL_RANGE   1u
+#define DSPMI_FIR_F32_PRODUCTS 2u
+int dspmi_fir_create_f32_opts(dspmi_fir_t *plan, const float *taps, unsigned nh, int device, unsigned options);
 /* An f64 plan sums in double with every product and every sum rounded on its own, in the
  * reference's order (bit for bit conv0 / conv1 / convolve); filters of up to 12 taps (more on
  * rows shorter than 2048 samples) take the same tile-free kernel as short f32 filters. */

@@ -555,3 +555,124 @@ def test_short_filters_as_a_stream_in_double(nh, nx, nchan, monkeypatch):
         assert np.array_equal(dsp_amd.conv1(xs, h), oracle.conv1(xs, h))
         assert np.array_equal(dsp_amd.convolve(xs, h, nx), oracle.convolve(xs, h, nx))
         assert np.array_equal(dsp_amd.convolve_alloc(xs, h), oracle.convolve(xs, h))
+
+
+# ---- what the f16 kernel does with samples it has no scale for ---------------------------
+
+def _nonfinite_reference(x, h, nxx):
+    """The reference's sum (fft/src/main.c:197-203) on a row with non-finite samples: which
+    outputs are finite, and their values (numpy warns about inf * 0; that NaN is the point)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        return oracle.fir_batch_f32(x, h, nxx)
+
+
+@pytest.mark.parametrize("nh", [33, 127, 305])
+def test_f16_kernel_confines_non_finite_samples_as_the_reference_does(nh):
+    """One NaN and one infinity, in different tiles of a row, near a tile edge and in the middle:
+    exactly the outputs whose nh samples include one of them are non-finite, as in the
+    reference's sum, and every other output keeps the usual accuracy -- the tile's scale does not
+    exist then, so the kernel sums such tiles tap by tap."""
+    rng = np.random.default_rng(nh)
+    nchan, nx = 3, 5 * 4096
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x[0, 4096 - 7] = np.nan          # reaches into the next tile
+    x[0, 3 * 4096 + 1000] = np.inf
+    x[1, 0] = -np.inf
+    x[1, nx - 1] = np.nan
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    hist[2, 5] = np.nan              # the carried history counts as samples too
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert "f16x2" in plan.variant
+    xd, hd = torch.from_numpy(x).cuda(), torch.from_numpy(hist).cuda()
+    for nxx, hh in ((nx, hd), (nx + nh, None)):
+        got = plan.exec(xd, nxx, hist=hh).cpu().numpy()
+        xin = x if hh is None else np.concatenate([hist, x], axis=1)
+        want = _nonfinite_reference(xin, h, xin.shape[1] + (nxx - nx))[:, xin.shape[1] - nx:]
+        assert want.shape == got.shape
+        bad = ~np.isfinite(want)
+        assert bad.any() and np.array_equal(~np.isfinite(got), bad), (nh, nxx, (np.isfinite(got) == bad).sum())
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(got[np.isinf(want)], want[np.isinf(want)].astype(np.float32))
+        for c in range(nchan):
+            ok = ~bad[c]
+            for a in range(0, nxx, 4096):
+                sel = ok[a:a + 4096]
+                with np.errstate(invalid="ignore"):
+                    err = np.linalg.norm((got[c, a:a + 4096] - want[c, a:a + 4096])[sel])
+                assert err <= TOL_FIR * np.linalg.norm(want[c, a:a + 4096][sel]), (nh, nxx, c, a, err)
+
+
+@pytest.mark.parametrize("nh", [33, 127])
+def test_f16_kernel_dynamic_range_inside_a_tile(nh, monkeypatch):
+    """One scale per tile: a sample 2^40 and more above its neighbours (a 1e6 spike in a 1e-6
+    signal, a 1e30 outlier in a signal of order 1) takes the neighbours' precision -- every output
+    is within 2^-37 sqrt(nh) max|h| of the TILE's largest sample, not of its own samples; tiles
+    without the outlier are unaffected.  A plan created with DSPMI_FIR_FULL_RANGE keeps the
+    usual bound relative to each output's own samples."""
+    rng = np.random.default_rng(nh + 1)
+    nx = 3 * 4096
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    for spike, level in ((1e6, 1e-6), (1e30, 1.0)):
+        x = (level * rng.uniform(-1, 1, (1, nx))).astype(np.float32)
+        k = 4096 + 2000
+        x[0, k] = spike
+        want = oracle.fir_batch_f32(x, h, nx)[0]
+        near = np.zeros(nx, bool)
+        near[k:k + nh] = True                       # outputs that see the spike
+        xd = torch.from_numpy(x).cuda()
+        half = dsp_amd.FirPlan(h, "f32")
+        assert "f16x2" in half.variant
+        got = half.exec(xd).cpu().numpy()[0]
+        # the outputs under the spike: relative to themselves (they are of the spike's order)
+        assert rel_l2(got[near], want[near]) <= TOL_FIR
+        # the rest of the spike's tile: the absolute bound of the contract
+        bound = 2.0 ** -37 * np.sqrt(nh) * np.abs(h).max() * spike
+        tile = np.zeros(nx, bool)
+        tile[4096:8192] = True
+        # (the window of the next tile starts up to 304 samples early: its scale sees the spike too
+        # if the spike lies that close to the edge; here it does not)
+        assert np.abs(got - want)[tile & ~near].max() <= bound
+        # tiles without the spike: untouched
+        for a in (0, 8192):
+            assert rel_l2(got[a:a + 4096], want[a:a + 4096]) <= TOL_FIR
+        # full range on request: every output relative to the samples under its own taps
+        full = dsp_amd.FirPlan(h, "f32", options=dsp_amd.FirPlan.FULL_RANGE)
+        assert "bf16x3" in full.variant
+        gf = full.exec(xd).cpu().numpy()[0]
+        far = tile & ~near
+        far[k - 64:k + nh + 64] = False             # (clear of the 16-output blocks around the spike)
+        assert rel_l2(gf[far], want[far]) <= TOL_FIR
+        assert rel_l2(gf[near], want[near]) <= TOL_FIR
+
+
+def test_plan_options_select_the_kernels():
+    h = oracle.windowed_sinc_taps(127).astype(np.float32)
+    assert "f16x2" in dsp_amd.FirPlan(h, "f32").variant
+    assert "bf16x3" in dsp_amd.FirPlan(h, "f32", options=dsp_amd.FirPlan.FULL_RANGE).variant
+    assert "mfma16x16x4" in dsp_amd.FirPlan(h, "f32", options=dsp_amd.FirPlan.F32_PRODUCTS).variant
+    # outside the f16 kernel's range the full-range option changes nothing
+    h16 = oracle.TAPS16.astype(np.float32)
+    assert dsp_amd.FirPlan(h16, "f32", options=dsp_amd.FirPlan.FULL_RANGE).variant == dsp_amd.FirPlan(h16, "f32").variant
+    with pytest.raises(dsp_amd.DspmiError):
+        dsp_amd.FirPlan(h, "f32", options=64)
+
+
+def test_fir_and_spectrum_kernel_with_a_non_finite_sample():
+    """The fused filter + spectrum kernel takes the same tap-by-tap path: the frame that holds the
+    filtered NaN has no finite spectrum, every other frame is what the two calls give."""
+    rng = np.random.default_rng(3)
+    nh, nfft = 127, 4096
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    x = rng.uniform(-1, 1, (2, 4 * nfft)).astype(np.float32)
+    x[0, nfft + 50] = np.nan
+    x[1, 2 * nfft - 3] = np.inf      # its filtered samples reach into frame 2
+    fir, fft = dsp_amd.FirPlan(h, "f32"), dsp_amd.FftPlan(nfft, "f32")
+    xd = torch.from_numpy(x).cuda()
+    got = fir.spectrum(fft, xd).cpu().numpy().reshape(2, 4, -1)
+    y = fir.exec(xd)
+    want = fft.r2c_spectrum(y.view(-1, nfft)).cpu().numpy().reshape(2, 4, -1)
+    for c, f in ((0, 1), (1, 1), (1, 2)):
+        assert not np.isfinite(got[c, f]).any()
+    for c, f in ((0, 0), (0, 2), (0, 3), (1, 0), (1, 3)):
+        assert np.isfinite(got[c, f]).all() and rel_l2(got[c, f], want[c, f]) <= 1e-5, (c, f)
