@@ -18,15 +18,24 @@ def shard_range(total, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def segment_length(nx, world):
+    """Outputs per rank when one signal of nx samples is cut for `world` ranks: every rank the same
+    count (the last one whatever remains), so that the gather is one all_gather of equal pieces
+    straight into the output buffer."""
+    return -(-nx // world)
+
+
 def segment_plan(nx, nh, world):
-    """Split the outputs [0, nx) of one long signal into `world` segments.
+    """Split the outputs [0, nx) of one long signal into `world` segments of segment_length(nx, world)
+    samples (the last one shorter, possibly empty).
 
     Returns a list of (out_lo, out_hi, in_lo): rank r computes outputs [out_lo, out_hi) and needs
     inputs [in_lo, out_hi) with in_lo = max(0, out_lo - (nh - 1)); samples before index 0 are the
     zero history of the reference's convolve (fft/src/main.c:199)."""
+    seg = segment_length(nx, world)
     plan = []
     for r in range(world):
-        lo, hi = shard_range(nx, world, r)
+        lo, hi = min(r * seg, nx), min((r + 1) * seg, nx)
         plan.append((lo, hi, max(0, lo - (nh - 1))))
     return plan
 
@@ -49,30 +58,35 @@ def filter_segment(plan, x_with_halo, out_lo, in_lo):
     before them, as segment_plan lays them out); plan: FirPlan or OlsPlan with .nh and
     .exec(x[nchan, nx], hist=).  Returns y[out_lo:out_hi]."""
     hist, body = split_history(x_with_halo, out_lo, in_lo, plan.nh)
+    if body.shape[-1] == 0:
+        return body.clone()
     return plan.exec(body[None, :].contiguous(), hist=hist[None, :].contiguous())[0]
 
 
 def gather_segments(y_local, nx, world=None, group=None):
-    """all_gather of the per-rank output segments into the full-length signal on every rank.
-
-    Segments differ in length by at most one sample, so they are padded to the longest for the
-    collective and trimmed afterwards.  One RCCL all_gather over xGMI; never a reduction."""
+    """The per-rank output segments (1-D, cut by segment_plan) put together on every rank: ONE
+    all_gather of equal pieces, received directly in the output buffer -- no staging copies, no
+    concatenation.  Returns a view of the first nx samples of that buffer.  Only the last rank,
+    whose segment may be shorter, sends a padded copy of its piece.  RCCL over xGMI under the nccl
+    backend; never a reduction.  (gloo, used to rehearse the multi-rank path on fewer GPUs than
+    ranks, has no collectives on device tensors: the pieces go through the host there.)"""
     if world is None:
         world = dist.get_world_size(group)
     if world == 1:
         return y_local
-    longest = -(-nx // world)
-    pad = torch.zeros(y_local.shape[:-1] + (longest,), dtype=y_local.dtype, device=y_local.device)
-    pad[..., :y_local.shape[-1]] = y_local
-    # gloo (CPU rehearsals of the multi-rank path, ranks sharing one GPU) has no all_gather of
-    # device tensors: stage through the host there; RCCL gathers device to device over xGMI
-    staged = pad.is_cuda and dist.get_backend(group) == "gloo"
-    send = pad.cpu() if staged else pad
-    parts = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(parts, send, group=group)
-    out = []
-    for r, p in enumerate(parts):
-        lo, hi = shard_range(nx, world, r)
-        out.append(p[..., :hi - lo])
-    full = torch.cat(out, dim=-1)
-    return full.to(y_local.device) if staged else full
+    assert y_local.dim() == 1
+    seg = segment_length(nx, world)
+    send = y_local.contiguous()
+    if send.shape[0] != seg:
+        send = torch.zeros((seg,), dtype=y_local.dtype, device=y_local.device)
+        send[:y_local.shape[0]] = y_local
+    if y_local.is_cuda and dist.get_backend(group) == "gloo":
+        full = torch.empty((world * seg,), dtype=y_local.dtype)
+        dist.all_gather(list(full.view(world, seg).unbind(0)), send.cpu(), group=group)
+        return full[:nx].to(y_local.device)
+    full = torch.empty((world * seg,), dtype=y_local.dtype, device=y_local.device)
+    if y_local.is_cuda:
+        dist.all_gather_into_tensor(full, send, group=group)
+    else:
+        dist.all_gather(list(full.view(world, seg).unbind(0)), send, group=group)
+    return full[:nx]

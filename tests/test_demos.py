@@ -20,7 +20,8 @@ def _build():
 
 def test_demos_compile_as_plain_c():
     _build()
-    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo", "firdesign_demo", "fft_tool", "filter_tool"):
+    for name in ("convolution_demo", "fir_demo", "filter_demo", "fftc_demo", "fftw_demo", "firdesign_demo", "fft_tool", "filter_tool",
+                 "multi_gpu_demo"):
         assert os.path.exists(os.path.join(BIN, name))
 
 
@@ -198,3 +199,61 @@ def test_filter_tool_matches_oracle(tmp_path):
         gains[int(np.floor(lo / fband)):min(int(np.ceil(hi / fband)), len(gains))] = g
     np.testing.assert_allclose(rows[:, 1], x[first:first + n], atol=6e-7)
     np.testing.assert_allclose(rows[:, 2], oracle.filter(x[first:first + n], gains), atol=6e-7)
+
+
+def _multi_gpu(tmp_path, mode, nshard, *sizes):
+    """demos/multi_gpu_demo.c: one host thread per shard, each with its own plan on its own device
+    (round robin: on a one-GPU box both shards share device 0).  Returns (input, output) as f32."""
+    path = os.path.join(str(tmp_path), "%s_%d.bin" % (mode, nshard))
+    r = _tool("multi_gpu_demo", mode, str(nshard), path, *[str(v) for v in sizes])
+    assert r.returncode == 0, r.stderr
+    assert ("%d shards" % nshard) in r.stdout
+    both = np.fromfile(path, dtype=np.float32)
+    return both[:len(both) // 2], both[len(both) // 2:], r.stdout
+
+
+def _lowpass(nh):
+    k = np.arange(nh, dtype=np.float64) - (nh - 1) / 2.0
+    h = np.sinc(2.0 * 6000.0 / 48000.0 * k) * (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(nh) / (nh - 1)))
+    return (h / h.sum()).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nshard", [1, 2, 3])
+def test_multi_gpu_demo_shards_channels_and_frames_from_c(tmp_path, nshard):
+    """Channel and frame sharding through include/dspmi.h alone (no Python, no collective): every
+    shard's rows against the oracle, whatever the number of shards."""
+    nchan, nx, nh = 7, 20000, 127
+    x, y, _ = _multi_gpu(tmp_path, "channels", nshard, nchan, nx, nh)
+    want = oracle.fir_batch_f32(x.reshape(nchan, nx), _lowpass(nh), nx)
+    for c in range(nchan):
+        for a in range(0, nx, 4096):
+            b = min(a + 4096, nx)
+            err = np.linalg.norm(y.reshape(nchan, nx)[c, a:b] - want[c, a:b]) / np.linalg.norm(want[c, a:b])
+            assert err <= 1e-6, (c, a, err)
+    nframe, n = 37, 1024
+    z, out, _ = _multi_gpu(tmp_path, "frames", nshard, nframe, n)
+    z = z.reshape(nframe, n, 2).astype(np.float64)
+    out = out.reshape(nframe, n, 2)
+    for f in (0, nframe // 2, nframe - 1):
+        want = oracle.dft(z[f, :, 0] + 1j * z[f, :, 1], -1, "direct")
+        got = out[f, :, 0] + 1j * out[f, :, 1]
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-5, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nshard,nh", [(2, 8191), (4, 2049), (1, 8191)])
+def test_multi_gpu_demo_splits_one_long_signal_from_c(tmp_path, nshard, nh):
+    """One signal, one long filter, one output segment per shard: a shard's slice carries the
+    nh-1 samples before its segment as history (fft/src/main.c:193-204 is the sum), and the
+    segments put together are the filtered signal -- per 4096-sample block against the oracle."""
+    nx = 262144 + 5
+    x, y, text = _multi_gpu(tmp_path, "split", nshard, nx, nh)
+    assert ("outputs [0, %d)" % (nx // nshard if nshard > 1 else nx)) in text
+    want = oracle.fir_batch_f32(x[None, :], _lowpass(nh), nx)[0]
+    scale = np.linalg.norm(want) / np.sqrt(nx)
+    for a in range(0, nx, 4096):
+        b = min(a + 4096, nx)
+        # (a row's first nh-1 outputs are a start-up transient: held to the steady-state blocks' absolute error)
+        err = np.linalg.norm(y[a:b] - want[a:b])
+        assert err <= 1e-6 * max(np.linalg.norm(want[a:b]), scale * np.sqrt(b - a)), (a, err)

@@ -61,9 +61,23 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_gloo_segments_and_channels(tmp_path):
+def test_segment_plan_cuts_equal_pieces():
+    for nx in (1, 9, 10, 4096, 5000, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            for nh in (1, 16, 8191):
+                plan = parallel.segment_plan(nx, nh, world)
+                seg = parallel.segment_length(nx, world)
+                assert plan[0][0] == 0 and plan[-1][1] == nx
+                assert all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+                assert all(hi - lo == seg for lo, hi, _ in plan[:-1] if hi < nx)       # equal pieces up to the last
+                assert all(0 <= hi - lo <= seg for lo, hi, _ in plan)
+                assert all(in_lo == max(0, lo - (nh - 1)) for lo, _, in_lo in plan)
+
+
+@pytest.mark.parametrize("world,nx", [(2, 5001), (3, 5000)])
+def test_gloo_ranks_segments_and_channels(tmp_path, world, nx):
     import oracle
-    world, nx, nh = 2, 5001, 257
+    nh = 257
     mp.spawn(_worker, args=(world, _free_port(), nx, nh, str(tmp_path)), nprocs=world, join=True)
     rng = np.random.default_rng(123)
     x = rng.uniform(-1, 1, nx).astype(np.float32)
