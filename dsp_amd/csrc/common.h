@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <unistd.h>
+
 #include "../../include/dspmi.h"
 
 namespace dspmi {
@@ -92,7 +94,9 @@ int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *
 
 // A size or argument the library refuses ends the program with status 255, the status the
 // reference's tools return on their own errors (util/fft/fft.c, util/filter/filter.c: return -1
-// from main); a device failure aborts.
+// from main); a device failure aborts.  The process ends with _exit after its output streams are
+// flushed: exit() would run the host program's atexit handlers and the HIP runtime's static
+// destructors from inside a library call, possibly with work still queued on the device.
 #define DSPMI_OR_DIE(call)                                                                   \
     do {                                                                                     \
         int r__ = (call);                                                                    \
@@ -100,6 +104,7 @@ int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *
             fprintf(stderr, "libdspmi: %s:%d: %s failed (%d): %s\n", __FILE__, __LINE__,     \
                     #call, r__, dspmi_last_error());                                         \
             if (r__ == DSPMI_EIO) abort();                                                   \
-            exit(255);                                                                       \
+            fflush(nullptr);                                                                 \
+            _exit(255);                                                                      \
         }                                                                                    \
     } while (0)

@@ -403,13 +403,15 @@ int run_pow2(const dspmi::FftKernel *k, const void *in, void *out, const void *t
 //   X[n2 k1 + k2] = sum_a W_n1^(a k1) . W_n^(a k2) . sum_b x[a + n1 b] W_n2^(b k2)
 // as transpose, n1 batched n2-point transforms, transpose with the W_n^(a k2) factors, n2 batched
 // n1-point transforms, transpose.  Frames go through in groups that keep the two work images
-// within `cap` bytes.
+// within `cap` bytes: 128 MiB of plan-owned scratch on the allocating path (kept until the plan is
+// destroyed; the passes are bound by their transposes, not by the group size), or the caller's
+// fixed work space.
 template <typename T>
 int four_step(dspmi_fft_plan *pl, const C<T> *in, C<T> *out, size_t batch, int backward, hipStream_t s, void *fixed_work,
               size_t fixed_bytes)
 {
     const size_t n = pl->n, frame_bytes = 2 * n * sizeof(C<T>);
-    size_t cap = fixed_work ? fixed_bytes : ((size_t)512 << 20);
+    size_t cap = fixed_work ? fixed_bytes : ((size_t)128 << 20);
     if (fixed_work && frame_bytes > cap)
         return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: one frame of n = %u needs %zu bytes of work space, the static scratch holds %zu",
                            pl->n, frame_bytes, cap);

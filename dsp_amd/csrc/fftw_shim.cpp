@@ -79,7 +79,8 @@ void dspmi_fftw_execute(const fftw_plan p)
         // the plan could not be made (the reference's wrappers do not check): report why and
         // leave with the status the reference's tools use for their own errors
         fprintf(stderr, "libdspmi: fftw_execute(NULL): %s\n", dspmi_last_error());
-        exit(255);
+        fflush(nullptr);
+        _exit(255);
     }
     DSPMI_HIP_OR_DIE(hipMemcpy(p->dev_in, p->host_in, p->in_bytes, hipMemcpyHostToDevice));
     switch (p->kind) {

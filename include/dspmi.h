@@ -74,7 +74,8 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  * 4096 outputs) of the double sum:
  *   up to 16 taps   f32 multiply-accumulate chains straight from global memory, four outputs per
  *                   lane (flags == 0, nxx == nx, rows on 16-byte boundaries; the next line's
- *                   kernel otherwise; also up to 32 taps on rows of fewer than 2048 samples);
+ *                   kernel otherwise; also 17 .. 24 taps on rows of fewer than 4096 samples and
+ *                   25 .. 32 taps on rows of fewer than 2048);
  *   up to 32 taps   f32 multiply-accumulate chains on the matrix unit;
  *   33 .. 305       the same sum through the f16 matrix pipe: samples and taps as two f16 parts
  *                   each, under one power-of-two scale per 4096-output tile (the tile's window of
@@ -242,11 +243,12 @@ const char *dspmi_fft_variant(dspmi_fft_t plan);
  * doc/notes:81-82) applied to overlapping blocks.  A plan holds H = FFT(taps)/N. */
 typedef struct dspmi_ols_plan *dspmi_ols_t;
 
-/* fft_n: block length in samples (power of two >= 2*nh, <= 32768), or 0 to choose.  Up to
- * 16384 two real blocks ride one fft_n-point complex transform; a 32768-sample block rides a
- * 16384-point transform on its own (even samples as real parts, odd samples as imaginary parts),
- * the default beyond 2048 taps.  DSPMI_OLS_REAL=0 in the environment at creation selects the
- * kernel that runs pairs of 32768-sample blocks through 32768-point transforms instead. */
+/* fft_n: block length in samples (power of two >= 2*nh, <= 32768), or 0 to choose.  Blocks of up
+ * to 8192 samples ride in pairs, two real blocks per fft_n-point complex transform; blocks of 16384
+ * and 32768 samples ride one each on a transform of half their length (even samples as real parts,
+ * odd samples as imaginary parts) -- 32768-sample blocks are the default beyond 2048 taps.
+ * DSPMI_OLS_REAL=0 in the environment at creation selects the kernels that run pairs of such
+ * blocks through full-length transforms instead. */
 int dspmi_ols_create_f32(dspmi_ols_t *plan, const float *taps, unsigned nh, unsigned fft_n, int device);
 int dspmi_ols_destroy(dspmi_ols_t plan);
 unsigned dspmi_ols_fft_length(dspmi_ols_t plan);

@@ -56,3 +56,23 @@ def test_no_alloc_c2c_in_place_and_limits():
     small = z[:2].clone()
     plan.c2c_noalloc(small, out=small)
     assert torch.equal(torch.view_as_real(small), torch.view_as_real(want[:2]))
+
+
+@pytest.mark.parametrize("n,dtype,batch", [(482, "f64", 40), (65536, "f32", 6)])
+def test_no_alloc_c2c_on_a_fresh_plan_leaves_device_memory_alone(n, dtype, batch):
+    """The first execute of a plan, before any dspmi_fft_exec_c2c has grown the plan's own work
+    buffers: the amount of free device memory is the same before and after (an entry point that fell
+    back to the plan's buffer would have had to allocate it), and the result is that of a second
+    plan's allocating execute, bit for bit."""
+    ct = np.complex128 if dtype == "f64" else np.complex64
+    z = _frames(batch, n, ct, n + batch)
+    got = torch.empty_like(z)
+    fresh = dsp_amd.FftPlan(n, dtype)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    fresh.c2c_noalloc(z, dsp_amd.FORWARD, out=got)
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, (free_before, free_after)
+    want = dsp_amd.FftPlan(n, dtype).c2c(z, dsp_amd.FORWARD)
+    assert torch.equal(torch.view_as_real(got), torch.view_as_real(want))
