@@ -800,6 +800,7 @@ __global__ __launch_bounds__(block_threads<NT>()) void fft_r2c_kernel(const C<T>
 template <int NS>
 struct SpectrumSink {
     static constexpr bool kTileHook = true;
+    static constexpr bool kRedo = false;     // a frame with a non-finite sample in its window: a spectrum of NaNs
     static constexpr bool kUnscaled = true;  // emit() takes the sums as they leave the matrix unit; the tile's factor goes into the spectrum's gain
     static constexpr int N = 2048, NT = 256, R0 = 8, R1 = 8, R2 = 8, R3 = 4, TW = 3, P = N / NT;
     C<float> *img;                    // the frame image, padded_len(N) complex

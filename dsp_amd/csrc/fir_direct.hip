@@ -742,6 +742,7 @@ __global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p
 struct StoreSink {
     static constexpr bool kTileHook = false;
     static constexpr bool kUnscaled = false;
+    static constexpr bool kRedo = true;
     const FirParams<float> &p;
     __amdgpu_buffer_rsrc_t yrsrc;
     __device__ __forceinline__ explicit StoreSink(const FirParams<float> &params) : p(params) {}
@@ -757,10 +758,34 @@ struct StoreSink {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, res), yrsrc, off, 0, 2);  // nontemporal
     }
     __device__ __forceinline__ void end_tile() {}
+    // A tile the walker had no scale for (an infinity or a NaN in its window), summed again tap by
+    // tap in f32 in the reference's order (fft/src/main.c:197-203): exactly the outputs whose nh
+    // samples include the non-finite one then are not finite, as in the reference.
+    __device__ void redo_tile(unsigned chan, long tile_start)
+    {
+        const long nx = p.nx, nh = p.nh;
+        const float *xr = p.x + (size_t)chan * p.x_stride;
+        const float *hr = p.hist ? p.hist + (size_t)chan * p.hist_stride + (nh - 1) : nullptr;
+        float *yr = p.y + (size_t)chan * p.y_stride;
+        const long end = tile_start + kSplitTile < (long)p.nxx ? tile_start + kSplitTile : (long)p.nxx;
+        for (long i = tile_start + threadIdx.x; i < end; i += 256) {
+            float acc = 0.f;
+            for (long j = 0; j < nh; j++) {
+                const long k = i - j;
+                float xv = 0.f;
+                if (k >= 0 && k < nx) xv = xr[k];
+                else if (k < 0 && hr) xv = hr[k];
+                acc = __builtin_fmaf(p.taps[j], xv, acc);
+            }
+            yr[i] = acc;
+        }
+    }
 };
 
+// (Four workgroups per CU up to five slices: at five the walker needs three registers fewer than
+// the compiler takes unasked, and finds them without spilling.)
 template <int NS>
-__global__ __launch_bounds__(256) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS <= 5 ? 4 : 3))) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     StoreSink sink(p);
@@ -1178,12 +1203,14 @@ int launch_half(FirParams<float> p, const void *tab, float unscale, int ns, unsi
     // a grid apart instead of consecutive ones changes nothing at these settings (16 taps, 16
     // tiles: 0.805 -> 0.762, level with 4 consecutive tiles' 0.748; 127 taps: 0.861 -> 0.866).
     unsigned tpb = (unsigned)(tiles / 8192);
-    const unsigned cap = ns > 6 ? 32 : ns > 4 ? 16 : 4;
+    // (five slices with four workgroups per CU: 8 tiles 0.787 ms, 4 tiles 0.789, 16 tiles 0.800)
+    const unsigned cap = ns > 6 ? 32 : ns > 5 ? 16 : ns > 4 ? 8 : 4;
     p.tiles_per_block = tpb < 2 ? (tiles >= 2048 ? 2 : 1) : (tpb > cap ? cap : tpb);
     {
         const char *env = getenv("DSPMI_FIR_TPB");  // experiment knob
         if (env && atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
     }
+    if (p.tiles_per_block > 64) p.tiles_per_block = 64;  // the walker's list of tiles to do over holds 64
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
     switch (ns) {
     case 1: return launch_half_t<1>(p, tab, unscale, blocks, stream);

@@ -147,7 +147,9 @@ struct ToneSource {
 // (the hook may use barriers itself).  Memory instructions in a sink must be unconditional: the
 // compiler's waits for the staging registers count the operations issued after each load, and
 // one load or store under a branch makes it wait for nearly everything (see fir_split_kernel).
-// LDS behind half_lds_bytes(NS) belongs to the sink.
+// LDS behind half_lds_bytes(NS) belongs to the sink.  A tile whose window holds an infinity or a
+// NaN has no scale: its results are emitted as NaN, and where Sink::kRedo is set
+// redo_tile(channel, first output) is called for it after the workgroup's last tile.
 template <int NS, class Sink, class Source>
 __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const u32x4 *__restrict__ htab, float tap_unscale,
                                                char *smem_raw, Sink &sink, const Source &src)
@@ -342,16 +344,23 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     };
     // the tile's scale, a power of two that brings its largest sample into [2^14, 2^15) (kept
     // within 2^-100 .. 2^100), and the factor that takes a sum of scaled products back
-    auto scales = [&](long tile_index, float &scale, float &unscale, bool &nonfinite) {
+    unsigned long long redo = 0;  // tiles of this workgroup (at most 64: the launchers see to it) whose windows held non-finite samples
+    auto scales = [&](long tile_index, float &scale, float &unscale) {
         const u32x4 m4 = *reinterpret_cast<const u32x4 *>(maxima + (tile_index & 1) * 4);
         const unsigned m01 = m4[0] > m4[1] ? m4[0] : m4[1], m23 = m4[2] > m4[3] ? m4[2] : m4[3];
         const unsigned m = m01 > m23 ? m01 : m23;
         const int mu = __builtin_amdgcn_readfirstlane((int)m);
-        nonfinite = MAXT == 0 && (unsigned)mu >= 0x7f800000u;  // an infinity or a NaN somewhere in the window
         int e = 268 - (int)((mu >> 23) & 0xff);
         e = e < 27 ? 27 : (e > 227 ? 227 : e);
         scale = __builtin_bit_cast(float, e << 23);
         unscale = __builtin_bit_cast(float, (254 - e) << 23) * tap_unscale;
+        // A window with an infinity or a NaN in it has no scale, and what the matrix unit makes of
+        // it means nothing: every result of the tile leaves as NaN (the factor is one), and the
+        // tile is remembered for the sink to do over once the walk is finished.
+        if ((unsigned)mu >= 0x7f800000u) {
+            unscale = __builtin_bit_cast(float, 0x7fc00000);
+            if (tile_index < 64) redo |= 1ull << tile_index;
+        }
     };
 
     // B operand: lane holds column a = lane&15 (block a of 16 outputs), window positions
@@ -373,8 +382,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     publish_max(0);
     __syncthreads();
     float scale_nxt, unscale_cur, unscale_nxt;
-    bool exact_cur, exact_nxt;
-    scales(0, scale_nxt, unscale_cur, exact_cur);
+    scales(0, scale_nxt, unscale_cur);
 #pragma unroll
     for (int it = 0; it < NIT; it++) put_piece(lds, it, scale_nxt);
     Unit nxt = describe();
@@ -396,8 +404,8 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         const unsigned short *rd_planes = lds + (unit & 1) * (2 * NSTAGE);
         unsigned short *wr_planes = lds + ((unit & 1) ^ 1) * (2 * NSTAGE);
         const Unit nxt2 = describe();
-        scales(unit + 1, scale_nxt, unscale_nxt, exact_nxt);
-        sink.begin_tile(cur.chan, cur.tile_start, exact_cur ? 1.f : unscale_cur);
+        scales(unit + 1, scale_nxt, unscale_nxt);
+        sink.begin_tile(cur.chan, cur.tile_start, unscale_cur);
         f16x8 xf[3][2];
         f32x4 big[4], small[4];
         const unsigned short *xp = rd_planes + b_base;
@@ -411,31 +419,6 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
             f32x4 res;
 #pragma unroll
             for (int r = 0; r < 4; r++) res[r] = Sink::kUnscaled ? big[q][r] + small[q][r] : (big[q][r] + small[q][r]) * unscale_cur;
-            if constexpr (MAXT == 0) {
-                // A window with an infinity or a NaN in it has no scale: its tile is summed tap by tap
-                // in f32 instead, as the reference sums (fft/src/main.c:197-203), so exactly the
-                // outputs whose nh samples include that one are not finite.  Rare, slow, and after
-                // it every earlier memory operation has landed.
-                if (exact_cur) {
-                    const long o0 = cur.tile_start + 1024 * (long)wave + 256 * q + 16 * (lane & 15) + 4 * (lane >> 4);
-                    const float *xr = p.x + (size_t)cur.chan * p.x_stride;
-                    const float *hr = p.hist ? p.hist + (size_t)cur.chan * p.hist_stride + (nh - 1) : nullptr;
-                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (long j = 0; j < nh; j++) {
-                        const float hj = p.taps[j];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const long k = o0 + r - j;
-                            float xv = 0.f;
-                            if (k >= 0 && k < nx) xv = xr[k];
-                            else if (k < 0 && hr) xv = hr[k];
-                            acc[r] = __builtin_fmaf(hj, xv, acc[r]);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; r++) res[r] = acc[r];
-                }
-            }
             sink.emit(q, res);
         };
         rd(0);
@@ -472,10 +455,23 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         cur = nxt;
         nxt = nxt2;
         unscale_cur = unscale_nxt;
-        exact_cur = exact_nxt;
     };
     iteration(0);  // a copy of the loop body, so that the loop is entered with its own order of memory operations
     for (long unit = 1; unit < nunits; unit++) iteration(unit);
+
+    // Here, with the walk over and its registers free, the rare path costs the walker nothing.
+    if constexpr (Sink::kRedo) {
+        if (redo) {
+            __builtin_amdgcn_s_waitcnt(0);  // the NaNs written above have landed: what follows overwrites them
+            __syncthreads();
+            for (long unit = 0; unit < nunits && unit < 64; unit++) {
+                if (!((redo >> unit) & 1)) continue;
+                const long tile = tile_lo + unit;
+                const unsigned chan = (unsigned)(tile / p.tiles_per_chan);
+                sink.redo_tile(chan, (tile - (long)chan * p.tiles_per_chan) * kSplitTile);
+            }
+        }
+    }
 }
 
 }  // namespace

@@ -113,7 +113,12 @@ def lib():
             pass
         L = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if not os.environ.get("DSPMI_LIB"):
+                    raise
+                continue   # another build, for A/B timing: it may predate an entry point
             fn.restype = res
             fn.argtypes = args
         _lib = L
@@ -148,7 +153,11 @@ class FirPlan:
             _check(lib().dspmi_fir_create_f64(C.byref(self._h), t.ctypes.data_as(_dp), self.nh, device), "fir_create_f64")
         else:
             t = np.ascontiguousarray(taps, dtype=np.float32)
-            _check(lib().dspmi_fir_create_f32_opts(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, device, options), "fir_create_f32")
+            if options == 0:
+                _check(lib().dspmi_fir_create_f32(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, device), "fir_create_f32")
+            else:
+                _check(lib().dspmi_fir_create_f32_opts(C.byref(self._h), t.ctypes.data_as(_fp), self.nh, device, options),
+                       "fir_create_f32_opts")
 
     @property
     def variant(self):
