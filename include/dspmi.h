@@ -297,7 +297,10 @@ int dspmi_fft_exec_r2c_spectrum_s16x2(dspmi_fft_t plan, const int16_t *in, float
  * written to memory.  fir: an f32 plan of up to 305 taps (the filter runs on the f16 matrix pipe
  * here whatever kernel the plan's own FIR calls take, with that kernel's properties); fft:
  * an f32 plan of 4096 points; nx a multiple of 4096.  DSPMI_ENOSYS for any other pair of plans:
- * the caller then makes the two calls. */
+ * the caller then makes the two calls.  A frame whose window of samples (its 4096 and the up to
+ * 304 before them that the kernel stages) holds an infinity or a NaN comes out as a spectrum of
+ * NaNs -- as the reference's transform of the filtered frame would, except when the non-finite
+ * sample lies in the few staged positions beyond the filter's reach. */
 int dspmi_fir_spectrum_f32(dspmi_fir_t fir, dspmi_fft_t fft, float *ps, unsigned nbin, int mode,
                            float scale, const float *x, size_t x_stride, unsigned nx, unsigned nchan,
                            const float *hist, size_t hist_stride, void *stream);
