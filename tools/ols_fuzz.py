@@ -21,6 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 ncase = 0
 worst = 0.0
+rel = {}
 while time.time() - t0 < budget:
     real = bool(rng.integers(0, 2))
     nh = int(rng.choice([2049, 4096, 8191, 16384, rng.integers(2049, 16385), rng.integers(2, 2049)]))
@@ -56,7 +57,14 @@ while time.time() - t0 < budget:
             for a in range(0, nx, 4096):
                 w = want[c, a:a + 4096]
                 err = np.linalg.norm(early[c, a:a + 4096] - w)
-                lim = 1e-6 * max(np.linalg.norm(w), np.linalg.norm(h) * np.sqrt(len(w) / 3.0))
+                # a full block of outputs that each see nh real samples: 1e-6 of the block's own norm, nothing
+                # added; blocks holding start-up outputs (no history, first nh-1 of the row) or fewer than 4096
+                # outputs: 1e-6 of the larger of their norm and the norm such a block has on average
+                steady = len(w) == 4096 and (use_hist or a >= nh - 1)
+                lim = 1e-6 * (np.linalg.norm(w) if steady else max(np.linalg.norm(w), np.linalg.norm(h) * np.sqrt(len(w) / 3.0)))
+                if np.linalg.norm(w) > 0:
+                    k = "steady" if steady else "startup/short"
+                    rel[k] = max(rel.get(k, 0.0), err / np.linalg.norm(w))
                 if err > lim:
                     print("FAIL: differs from the five-kernel composition", dict(real=real, nh=nh, nx=nx, nchan=nchan, grid=grid, hist=use_hist, chan=c, block=a, err=err, lim=lim), flush=True)
                     sys.exit(1)
@@ -64,4 +72,5 @@ while time.time() - t0 < budget:
     ncase += 1
     if ncase % 25 == 0:
         print("%d cases, %.0f s" % (ncase, time.time() - t0), flush=True)
-print("ok: %d cases in %.0f s; worst block difference from the composition %.2f of the bound" % (ncase, time.time() - t0, worst))
+print("ok: %d cases in %.0f s; worst block difference from the composition %.2f of the bound; relative to the block's own norm:" % (ncase, time.time() - t0, worst),
+      {k: "%.2e" % v for k, v in rel.items()})
