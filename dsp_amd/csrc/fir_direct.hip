@@ -739,6 +739,7 @@ __global__ __launch_bounds__(256) void fir_split_kernel(const FirParams<float> p
 
 // Results leave through a descriptor over the tile's part of the row: the row's ragged end
 // needs no branch, and only 4-byte alignment.
+template <int TILE>
 struct StoreSink {
     static constexpr bool kTileHook = false;
     static constexpr bool kUnscaled = false;
@@ -749,12 +750,12 @@ struct StoreSink {
     __device__ __forceinline__ void begin_tile(unsigned chan, long tile_start, float)
     {
         const long left = (long)p.nxx - tile_start;
-        yrsrc = uniform_descriptor(p.y + (size_t)chan * p.y_stride + tile_start, (int)(left < kSplitTile ? left : kSplitTile) * 4);
+        yrsrc = uniform_descriptor(p.y + (size_t)chan * p.y_stride + tile_start, (int)(left < TILE ? left : TILE) * 4);
     }
     __device__ __forceinline__ void emit(int q, f32x4 res)
     {
         const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int off = (int)(wave * 1024 + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) * 4;
+        const int off = (int)(wave * (TILE / 4) + q * 256 + 16 * (lane & 15) + 4 * (lane >> 4)) * 4;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, res), yrsrc, off, 0, 2);  // nontemporal
     }
     __device__ __forceinline__ void end_tile() {}
@@ -767,7 +768,7 @@ struct StoreSink {
         const float *xr = p.x + (size_t)chan * p.x_stride;
         const float *hr = p.hist ? p.hist + (size_t)chan * p.hist_stride + (nh - 1) : nullptr;
         float *yr = p.y + (size_t)chan * p.y_stride;
-        const long end = tile_start + kSplitTile < (long)p.nxx ? tile_start + kSplitTile : (long)p.nxx;
+        const long end = tile_start + TILE < (long)p.nxx ? tile_start + TILE : (long)p.nxx;
         for (long i = tile_start + threadIdx.x; i < end; i += 256) {
             float acc = 0.f;
             for (long j = 0; j < nh; j++) {
@@ -784,12 +785,12 @@ struct StoreSink {
 
 // (Four workgroups per CU up to five slices: at five the walker needs three registers fewer than
 // the compiler takes unasked, and finds them without spilling.)
-template <int NS>
+template <int NS, int TILE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS <= 5 ? 4 : 3))) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    StoreSink sink(p);
-    fir_half_tiles<NS>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
+    StoreSink<TILE> sink(p);
+    fir_half_tiles<NS, StoreSink<TILE>, MemorySource, TILE>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
 }
 
 }  // namespace
@@ -1165,10 +1166,23 @@ std::vector<unsigned short> half_tap_images(const float *taps, unsigned nh, int 
     return img;
 }
 
-template <int NS>
+// Which tile a row length gets.  Measured (2^27 samples as rows of 256 ... 16384, 33 / 127 / 305
+// taps): a row costs a fixed amount per tile it touches -- in the ratio 1 : 0.58 : 0.42 for tiles
+// of 4096 : 2048 : 1024 outputs, whatever the tap count -- plus the same amount per sample for
+// every tile size (a partly filled tile moves only the samples that exist), so the tile with the
+// smallest tiles-times-weight wins; ties go to the longer tile.
+int half_tile_for_rows(unsigned nxx, int)
+{
+    const unsigned long long n = nxx;
+    const unsigned long long c4 = (n + 4095) / 4096 * 100, c2 = (n + 2047) / 2048 * 58, c1 = (n + 1023) / 1024 * 42;
+    if (c4 <= c2 && c4 <= c1) return 4096;
+    return c2 <= c1 ? 2048 : 1024;
+}
+
+template <int NS, int TILE>
 int launch_half_t(const FirParams<float> &p, const void *tab, float unscale, unsigned blocks, hipStream_t stream)
 {
-    size_t lds = half_lds_bytes(NS);
+    size_t lds = half_lds_bytes(NS, TILE);
     {
         const char *env = getenv("DSPMI_FIR_BPC");  // experiments: cap the resident workgroups per CU
         if (env && atoi(env) > 0) {
@@ -1176,7 +1190,7 @@ int launch_half_t(const FirParams<float> &p, const void *tab, float unscale, uns
             if (want > lds) lds = want;
         }
     }
-    auto kern = fir_half_kernel<NS>;
+    auto kern = fir_half_kernel<NS, TILE>;
     static dspmi::PerDeviceOnce attr;
     if (attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1187,25 +1201,27 @@ int launch_half_t(const FirParams<float> &p, const void *tab, float unscale, uns
     return DSPMI_OK;
 }
 
-int launch_half(FirParams<float> p, const void *tab, float unscale, int ns, unsigned nchan, hipStream_t stream)
+template <int TILE>
+int launch_half_tile(FirParams<float> p, const void *tab, float unscale, int ns, unsigned nchan, hipStream_t stream)
 {
-    p.tiles_per_chan = (unsigned)(((unsigned long long)p.nxx + kSplitTile - 1) / kSplitTile);
+    p.tiles_per_chan = (unsigned)(((unsigned long long)p.nxx + TILE - 1) / TILE);
     const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
     if (tiles == 0) return DSPMI_OK;
     if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
     p.ntiles_total = (unsigned)tiles;
     // A workgroup's first two tiles are loaded with nothing to overlap them, which asks for long
     // walks; an HBM-bound stream runs fastest as many short-lived workgroups.  Measured on 131072
-    // tiles (one box): up to four slices (113 taps) 4 tiles per workgroup (33 taps 0.745 ms, 113
-    // taps 0.789; with 8 tiles 0.79, with 16 0.805 whatever the tap count), five and six slices 16
-    // (127 taps 0.806 ms; 0.864 with 4, 0.82 with 32, 0.86 with 171 = one resident set walking
-    // everything), 32 beyond (305 taps: 1.06 ms against 1.07 with 16).  Handing a workgroup tiles
-    // a grid apart instead of consecutive ones changes nothing at these settings (16 taps, 16
-    // tiles: 0.805 -> 0.762, level with 4 consecutive tiles' 0.748; 127 taps: 0.861 -> 0.866).
-    unsigned tpb = (unsigned)(tiles / 8192);
-    // (five slices with four workgroups per CU: 8 tiles 0.787 ms, 4 tiles 0.789, 16 tiles 0.800)
+    // tiles of 4096 outputs (one box): up to four slices (113 taps) 4 tiles per workgroup (33 taps
+    // 0.745 ms, 113 taps 0.789; with 8 tiles 0.79, with 16 0.805 whatever the tap count), five
+    // slices with four workgroups per CU 8 (0.787 ms; 4 tiles 0.789, 16 tiles 0.800), six 16, and
+    // 32 beyond (305 taps: 1.06 ms against 1.07 with 16).  Handing a workgroup tiles a grid apart
+    // instead of consecutive ones changes nothing at these settings (16 taps, 16 tiles: 0.805 ->
+    // 0.762, level with 4 consecutive tiles' 0.748; 127 taps: 0.861 -> 0.866).  Short tiles walk
+    // as many outputs per workgroup as long ones.
+    const unsigned per = kSplitTile / TILE;
+    unsigned tpb = (unsigned)(tiles / (8192 * per));
     const unsigned cap = ns > 6 ? 32 : ns > 5 ? 16 : ns > 4 ? 8 : 4;
-    p.tiles_per_block = tpb < 2 ? (tiles >= 2048 ? 2 : 1) : (tpb > cap ? cap : tpb);
+    p.tiles_per_block = (tpb < 2 ? (tiles >= 2048 * per ? 2 : 1) : (tpb > cap ? cap : tpb)) * per;
     {
         const char *env = getenv("DSPMI_FIR_TPB");  // experiment knob
         if (env && atoi(env) > 0) p.tiles_per_block = (unsigned)atoi(env);
@@ -1213,18 +1229,32 @@ int launch_half(FirParams<float> p, const void *tab, float unscale, int ns, unsi
     if (p.tiles_per_block > 64) p.tiles_per_block = 64;  // the walker's list of tiles to do over holds 64
     const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
     switch (ns) {
-    case 1: return launch_half_t<1>(p, tab, unscale, blocks, stream);
-    case 2: return launch_half_t<2>(p, tab, unscale, blocks, stream);
-    case 3: return launch_half_t<3>(p, tab, unscale, blocks, stream);
-    case 4: return launch_half_t<4>(p, tab, unscale, blocks, stream);
-    case 5: return launch_half_t<5>(p, tab, unscale, blocks, stream);
-    case 6: return launch_half_t<6>(p, tab, unscale, blocks, stream);
-    case 7: return launch_half_t<7>(p, tab, unscale, blocks, stream);
-    case 8: return launch_half_t<8>(p, tab, unscale, blocks, stream);
-    case 9: return launch_half_t<9>(p, tab, unscale, blocks, stream);
-    case 10: return launch_half_t<10>(p, tab, unscale, blocks, stream);
+    case 1: return launch_half_t<1, TILE>(p, tab, unscale, blocks, stream);
+    case 2: return launch_half_t<2, TILE>(p, tab, unscale, blocks, stream);
+    case 3: return launch_half_t<3, TILE>(p, tab, unscale, blocks, stream);
+    case 4: return launch_half_t<4, TILE>(p, tab, unscale, blocks, stream);
+    case 5: return launch_half_t<5, TILE>(p, tab, unscale, blocks, stream);
+    case 6: return launch_half_t<6, TILE>(p, tab, unscale, blocks, stream);
+    case 7: return launch_half_t<7, TILE>(p, tab, unscale, blocks, stream);
+    case 8: return launch_half_t<8, TILE>(p, tab, unscale, blocks, stream);
+    case 9: return launch_half_t<9, TILE>(p, tab, unscale, blocks, stream);
+    case 10: return launch_half_t<10, TILE>(p, tab, unscale, blocks, stream);
     }
     return dspmi::fail(DSPMI_EINVAL, "fir: no f16 kernel of %d slices", ns);
+}
+
+// Tiles of 4096 outputs, or of 1024 / 2048 where the rows would leave much of a long tile empty.
+int launch_half(const FirParams<float> &p, const void *tab, float unscale, int ns, unsigned nchan, hipStream_t stream)
+{
+    int tile = kSplitTile;
+    if (const char *env = getenv("DSPMI_FIR_TILE")) {  // experiment knob: 1024, 2048 or 4096
+        if (atoi(env) == 1024 || atoi(env) == 2048) tile = atoi(env);
+    } else {
+        tile = half_tile_for_rows(p.nxx, ns);
+    }
+    if (tile == 1024) return launch_half_tile<1024>(p, tab, unscale, ns, nchan, stream);
+    if (tile == 2048) return launch_half_tile<2048>(p, tab, unscale, ns, nchan, stream);
+    return launch_half_tile<kSplitTile>(p, tab, unscale, ns, nchan, stream);
 }
 
 template <int NS>

@@ -66,7 +66,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_descriptor(const void 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr size_t half_lds_bytes(int ns) { return (size_t)2 * 2 * (kSplitTile + 32 * ns - 16) * 2 + 64; }  // two sets of two planes + the maxima (a multiple of 64)
+constexpr size_t half_lds_bytes(int ns, int tile = kSplitTile) { return (size_t)2 * 2 * (tile + 32 * ns - 16) * 2 + 64; }  // two sets of two planes + the maxima (a multiple of 64)
 
 // f16(lo) in the low half, f16(hi) in the high half, both rounded to nearest even
 __device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi)
@@ -150,16 +150,22 @@ struct ToneSource {
 // LDS behind half_lds_bytes(NS) belongs to the sink.  A tile whose window holds an infinity or a
 // NaN has no scale: its results are emitted as NaN, and where Sink::kRedo is set
 // redo_tile(channel, first output) is called for it after the workgroup's last tile.
-template <int NS, class Sink, class Source>
+// TILE: outputs per workgroup step, 1024 BLK with BLK = 4 (the default), 2 or 1 blocks of 256
+// outputs per wave: rows much shorter than 4096 samples fill short tiles where they would leave
+// most of a long one empty (the sink numbers its outputs by the same TILE).
+template <int NS, class Sink, class Source, int TILE = kSplitTile>
 __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const u32x4 *__restrict__ htab, float tap_unscale,
                                                char *smem_raw, Sink &sink, const Source &src)
 {
     constexpr int MAXT = Source::kTones;  // 0: samples from memory
     constexpr int P = 32 * NS - 16;          // window positions ahead of a block's first output
-    constexpr int NSTAGE = kSplitTile + P;   // samples staged per tile (a multiple of 16)
+    constexpr int BLK = TILE / 1024;          // blocks of 256 outputs per wave and tile
+    static_assert(TILE == 1024 * BLK && (BLK == 1 || BLK == 2 || BLK == 4), "tiles of 1024, 2048 or 4096 outputs");
+    static_assert(MAXT == 0 || TILE == kSplitTile, "the tone source fills whole 4096-output tiles");
+    constexpr int NSTAGE = TILE + P;          // samples staged per tile (a multiple of 16)
     constexpr int NQ = NSTAGE / 4;           // ... in groups of four
     constexpr int NIT = (NQ + 255) / 256;    // groups per lane (the last one on a few lanes only)
-    constexpr int NSTEP = 4 * NS;            // MFMA steps per wave and tile
+    constexpr int NSTEP = BLK * NS;          // MFMA steps per wave and tile
     static_assert(P / 4 <= 256, "the history falls into every lane's first group");
     unsigned short *lds = reinterpret_cast<unsigned short *>(smem_raw);  // [2][2][NSTAGE]
     unsigned *maxima = reinterpret_cast<unsigned *>(lds + 4 * NSTAGE);    // [2][4]: per tile parity, per wave; magnitudes as bit patterns
@@ -201,7 +207,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         const bool valid = described++ < nunits;  // a tile past this workgroup's last reads nothing
         d.chan = valid ? cur_chan : 0;
         d.tile = valid ? cur_tile : 0;
-        d.tile_start = (long)cur_tile * kSplitTile;
+        d.tile_start = (long)cur_tile * TILE;
         d.hard = true;
         d.obase = nullptr;
         d.obytes = 0;
@@ -365,7 +371,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
 
     // B operand: lane holds column a = lane&15 (block a of 16 outputs), window positions
     // 8*(lane>>4) .. +7 of each slice
-    const unsigned b_base = wave * 1024 + 16 * (lane & 15) + 8 * (lane >> 4);
+    const unsigned b_base = wave * (256 * BLK) + 16 * (lane & 15) + 8 * (lane >> 4);
 
     // prologue: the first tile is split with nothing to overlap it, the second is on its way
     Unit cur = describe();
@@ -407,7 +413,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         scales(unit + 1, scale_nxt, unscale_nxt);
         sink.begin_tile(cur.chan, cur.tile_start, unscale_cur);
         f16x8 xf[3][2];
-        f32x4 big[4], small[4];
+        f32x4 big[BLK], small[BLK];
         const unsigned short *xp = rd_planes + b_base;
         auto rd = [&](int step) {
             const int off = 256 * (step / NS) + 32 * (step % NS);
@@ -447,7 +453,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
             __builtin_amdgcn_sched_barrier(0);
             if (s == 0 && q > 0) store(q - 1);
         }
-        store(3);
+        store(BLK - 1);
         if constexpr (MAXT > 0) fill(nxt2);
         if (unit + 1 < nunits) publish_max(unit + 2);
         if (Sink::kTileHook || unit + 1 < nunits) __syncthreads();  // the other planes and the maxima are complete, and every wave has left these planes
@@ -468,7 +474,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
                 if (!((redo >> unit) & 1)) continue;
                 const long tile = tile_lo + unit;
                 const unsigned chan = (unsigned)(tile / p.tiles_per_chan);
-                sink.redo_tile(chan, (tile - (long)chan * p.tiles_per_chan) * kSplitTile);
+                sink.redo_tile(chan, (tile - (long)chan * p.tiles_per_chan) * TILE);
             }
         }
     }

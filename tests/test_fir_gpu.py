@@ -676,3 +676,32 @@ def test_fir_and_spectrum_kernel_with_a_non_finite_sample():
         assert not np.isfinite(got[c, f]).any()
     for c, f in ((0, 0), (0, 2), (0, 3), (1, 0), (1, 3)):
         assert np.isfinite(got[c, f]).all() and rel_l2(got[c, f], want[c, f]) <= 1e-5, (c, f)
+
+
+@pytest.mark.parametrize("nh", [33, 127, 305])
+@pytest.mark.parametrize("nx", [100, 256, 1000, 1024, 1025, 1536, 2048, 2100, 3072, 5120, 6000])
+def test_f16_kernel_tiles_by_row_length(nh, nx, monkeypatch):
+    """Rows shorter than the walker's 4096-output tiles run through tiles of 1024 or 2048 outputs
+    (the plan's choice by row length); every tile size on every row length gives the same outputs
+    as the oracle per block -- many rows per launch, so that workgroups walk from row to row, with
+    carried history and with the nx + nh tail."""
+    rng = np.random.default_rng(nh * 7 + nx)
+    nchan = 37
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    plan = dsp_amd.FirPlan(h, "f32")
+    assert "f16x2" in plan.variant
+    xd, hd = torch.from_numpy(x).cuda(), torch.from_numpy(hist).cuda()
+    want_h = oracle.fir_batch_f32(np.concatenate([hist, x], axis=1), h, nh - 1 + nx)[:, nh - 1:]
+    want_0 = oracle.fir_batch_f32(x, h, nx + nh)
+    for tile in (None, "1024", "2048", "4096"):
+        if tile is None:
+            monkeypatch.delenv("DSPMI_FIR_TILE", raising=False)
+        else:
+            monkeypatch.setenv("DSPMI_FIR_TILE", tile)
+        got_h = plan.exec(xd, nx, hist=hd).cpu().numpy()
+        got_0 = plan.exec(xd, nx + nh).cpu().numpy()
+        for c in (0, 1, nchan // 2, nchan - 1):
+            assert_blocks(got_h[c], want_h[c], h, x[c], (tile, nh, nx, c, "history"))
+            assert_blocks(got_0[c], want_0[c], h, x[c], (tile, nh, nx, c, "tail"))
