@@ -410,8 +410,38 @@ template <typename T>
 int four_step(dspmi_fft_plan *pl, const C<T> *in, C<T> *out, size_t batch, int backward, hipStream_t s, void *fixed_work,
               size_t fixed_bytes)
 {
-    const size_t n = pl->n, frame_bytes = 2 * n * sizeof(C<T>);
+    const size_t n = pl->n;
     size_t cap = fixed_work ? fixed_bytes : ((size_t)128 << 20);
+    // Single precision, both factors 256 .. 1024 points (n = 2^16 .. 2^20): two passes, the
+    // transposes folded into the transforms' loads and stores (fft_c2c_bundle_kernel), one work
+    // frame.  DSPMI_FFT_FIVE_PASS=1 keeps the five-pass route below for A/B.
+    if constexpr (sizeof(T) == 4) {
+        const dspmi::fft_bundle_fn pass1 = dspmi::fft_bundle_find(pl->n2), pass2 = dspmi::fft_bundle_find(pl->n1);
+        if (pass1 && pass2 && !getenv("DSPMI_FFT_FIVE_PASS")) {
+            const size_t fb = n * sizeof(C<T>);
+            if (fixed_work && fb > cap)
+                return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: one frame of n = %u needs %zu bytes of work space, the static scratch holds %zu",
+                                   pl->n, fb, cap);
+            size_t group = cap / fb;
+            if (group < 1) group = 1;
+            if (group > batch) group = batch;
+            C<T> *w = static_cast<C<T> *>(fixed_work);
+            if (!fixed_work) {
+                int rc = ensure_work(pl, 4, group * fb);
+                if (rc != DSPMI_OK) return rc;
+                w = static_cast<C<T> *>(pl->work[4]);
+            }
+            for (size_t done = 0; done < batch; done += group) {
+                const size_t g = batch - done < group ? batch - done : group;
+                int rc = pass1(in + done * n, w, pl->tw_n2, g, pl->n1, pl->tw_hi, pl->tw_lo, pl->tw_shift, 1, backward, pl->num_cu, s);
+                if (rc != DSPMI_OK) return rc;
+                rc = pass2(w, out + done * n, pl->tw_n1, g, pl->n2, pl->tw_hi, pl->tw_lo, pl->tw_shift, 2, backward, pl->num_cu, s);
+                if (rc != DSPMI_OK) return rc;
+            }
+            return DSPMI_OK;
+        }
+    }
+    const size_t frame_bytes = 2 * n * sizeof(C<T>);
     if (fixed_work && frame_bytes > cap)
         return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: one frame of n = %u needs %zu bytes of work space, the static scratch holds %zu",
                            pl->n, frame_bytes, cap);

@@ -2425,6 +2425,129 @@ int launch_c2c_rows(const void *in, void *out, const void *tw, size_t batch, int
 }
 
 // ---------------------------------------------------------------------------
+// long transforms in two passes: the transposes folded into the transforms' loads and stores
+// ---------------------------------------------------------------------------
+
+// n = n1 n2 points, x[a + n1 b] -> X[n2 k1 + k2]:
+//   X[n2 k1 + k2] = sum_a W_n1^(a k1) . W_n^(a k2) . sum_b x[a + n1 b] W_n2^(b k2)
+// Pass 1 (MODE 1, N = n2, ncol = n1) transforms COLUMNS of the frame seen as [n2][n1]: a workgroup
+// takes FPB adjacent columns, moves them as rows of FPB contiguous points (64 or 128 bytes) through
+// the frames' LDS images -- the transposes of the five-pass scheme, done on chip --, multiplies
+// by W_n^(a k2) and puts the columns back where they came from (in a work frame).  Pass 2
+// (MODE 2, N = n1, ncol = n2) reads FPB adjacent ROWS of that work frame -- contiguous n1-point
+// frames -- and stores their transforms as columns of the output seen as [n1][n2].  Two passes over
+// memory instead of five.  The backward transform conjugates on the way in (pass 1) and on the way
+// out (pass 2).  W_n^e = twa[e >> shift] . twb[e & mask], as in transpose_kernel.
+template <int N, int NT, int R0, int R1, int R2, int R3, int MODE>
+__global__ __launch_bounds__((c2c_block_threads<float, N, NT>())) void fft_c2c_bundle_kernel(const C<float> *in, C<float> *out,
+                                                                             const C<float> *__restrict__ tw, size_t nbundle,
+                                                                             unsigned ncol, const C<float> *__restrict__ twa,
+                                                                             const C<float> *__restrict__ twb, unsigned shift,
+                                                                             int backward)
+{
+    typedef float T;
+    static_assert(NT <= 64, "a frame inside one wave");
+    constexpr int TW = 2;
+    constexpr int P = N / NT;
+    constexpr int BT = c2c_block_threads<T, N, NT>();
+    constexpr int FPB = BT / NT;
+    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
+    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
+    constexpr int NSLAST = N / RLAST;
+    static_assert(N * FPB == P * BT, "every lane moves P points of the bundle");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned slot = threadIdx.x / NT, tl = threadIdx.x % NT;
+    C<T> *img0 = reinterpret_cast<C<T> *>(smem_raw);
+    C<T> *lds = img0 + (size_t)slot * padded_len(N);
+    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
+    setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    const T sgn = backward ? T(-1) : T(1);
+    const unsigned bpf = ncol / FPB;  // bundles per frame
+
+    for (size_t g = blockIdx.x; g < nbundle; g += gridDim.x) {
+        const size_t F = g / bpf;
+        const unsigned c0 = (unsigned)(g - F * bpf) * FPB;
+        const size_t base = F * (size_t)N * ncol;
+        C<T> v[P];
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const unsigned e = threadIdx.x + BT * i, row = e / FPB, c = e % FPB;
+                img0[c * padded_len(N) + pad(row)] = nt_load(&in[base + (size_t)row * ncol + c0 + c]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < P / R0; b++)
+#pragma unroll
+                for (int r = 0; r < R0; r++) {
+                    C<T> q = lds[pad(tl + NT * b + r * (N / R0))];
+                    q.im *= sgn;
+                    v[b * R0 + r] = q;
+                }
+            frame_sync<NT>();  // the frame's own lanes have read it before its passes write it
+        } else {
+            const C<T> *src = in + base + (size_t)(c0 + slot) * N;
+#pragma unroll
+            for (int b = 0; b < P / R0; b++)
+#pragma unroll
+                for (int r = 0; r < R0; r++) v[b * R0 + r] = nt_load(&src[tl + NT * b + r * (N / R0)]);
+        }
+        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
+        frame_sync<NT>();
+        // results to their natural places in the frame's image
+#pragma unroll
+        for (int b = 0; b < P / RLAST; b++)
+#pragma unroll
+            for (int r = 0; r < RLAST; r++) {
+                const unsigned k = tl + NT * b + r * NSLAST;
+                C<T> q = v[b * RLAST + r];
+                if constexpr (MODE == 1) {
+                    const unsigned e = (c0 + slot) * k;  // < n
+                    q = cmul(q, cmul(twa[e >> shift], twb[e & ((1u << shift) - 1)]));
+                } else {
+                    q.im *= sgn;
+                }
+                lds[pad(k)] = q;
+            }
+        __syncthreads();
+        // ... and out as rows of FPB adjacent columns
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const unsigned e = threadIdx.x + BT * i, row = e / FPB, c = e % FPB;
+            nt_store(img0[c * padded_len(N) + pad(row)], &out[base + (size_t)row * ncol + c0 + c]);
+        }
+        __syncthreads();  // the images are free for the next bundle
+    }
+}
+
+template <int N, int NT, int R0, int R1, int R2, int R3>
+int launch_c2c_bundle(const void *in, void *out, const void *tw, size_t nframe, unsigned ncol, const void *twa, const void *twb,
+                      unsigned shift, int mode, int backward, int num_cu, hipStream_t s)
+{
+    constexpr int BT = c2c_block_threads<float, N, NT>();
+    constexpr int FPB = BT / NT;
+    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(2, R0, R1, R2, R3, N)) * sizeof(C<float>);
+    auto k1 = fft_c2c_bundle_kernel<N, NT, R0, R1, R2, R3, 1>;
+    auto k2 = fft_c2c_bundle_kernel<N, NT, R0, R1, R2, R3, 2>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    if (ncol % FPB) return dspmi::fail(DSPMI_EINVAL, "fft: %u columns do not divide into bundles of %d", ncol, FPB);
+    const size_t nbundle = nframe * (ncol / FPB);
+    if (nbundle == 0) return DSPMI_OK;
+    const size_t grid = nbundle < 0x7fffffffu ? nbundle : 0x7fffffffu;  // one bundle per workgroup: the dispatcher keeps the chip filled
+    hipLaunchKernelGGL(mode == 1 ? k1 : k2, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<float> *>(in),
+                       static_cast<C<float> *>(out), static_cast<const C<float> *>(tw), nbundle, ncol,
+                       static_cast<const C<float> *>(twa), static_cast<const C<float> *>(twb), shift, backward);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+// ---------------------------------------------------------------------------
 // launchers and the kernel table
 // ---------------------------------------------------------------------------
 
@@ -2655,6 +2778,16 @@ int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s)
 
 
 const FftKernel *fft_find(unsigned n, int precision) { return find_entry(n, precision); }
+
+fft_bundle_fn fft_bundle_find(unsigned n)
+{
+    switch (n) {
+    case 256: return launch_c2c_bundle<256, 16, 16, 16, 1, 1>;
+    case 512: return launch_c2c_bundle<512, 32, 16, 16, 2, 1>;
+    case 1024: return launch_c2c_bundle<1024, 64, 16, 16, 4, 1>;
+    }
+    return nullptr;
+}
 
 bluestein_launch_fn bluestein_find(unsigned m, int precision)
 {

@@ -371,6 +371,26 @@ def test_c2c_long_powers_of_two(dtype, n, batch):
     assert rel_l2(buf.cpu().numpy() / n, z) <= 4 * tol
 
 
+@pytest.mark.parametrize("n,batch", [(1 << 16, 5), (1 << 17, 3), (1 << 18, 2), (1 << 19, 2), (1 << 20, 3), (1 << 21, 1)])
+def test_c2c_long_transforms_in_two_passes(n, batch, monkeypatch):
+    """Single precision, 2^16 .. 2^20 points: two passes with the transposes folded into the
+    transforms' loads and stores; 2^21 and beyond, and DSPMI_FFT_FIVE_PASS=1, take the five-pass
+    route.  Both against the oracle per frame, forward and backward, and against each other."""
+    rng = np.random.default_rng(n)
+    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
+    zd = torch.from_numpy(z).cuda()
+    plan = dsp_amd.FftPlan(n, "f32")
+    for sign in (dsp_amd.FORWARD, dsp_amd.BACKWARD):
+        monkeypatch.delenv("DSPMI_FFT_FIVE_PASS", raising=False)
+        two = plan.c2c(zd, sign).cpu().numpy()
+        monkeypatch.setenv("DSPMI_FFT_FIVE_PASS", "1")
+        five = plan.c2c(zd, sign).cpu().numpy()
+        want = oracle.dft(z[batch - 1].astype(np.complex128), sign, "radix2")
+        assert rel_l2(two[batch - 1], want) <= TOL_FFT and rel_l2(five[batch - 1], want) <= TOL_FFT
+        for f in range(batch):
+            assert rel_l2(two[f], five[f].astype(np.complex128)) <= 1e-6, (n, sign, f)
+
+
 @pytest.mark.parametrize("dtype,n", [("f64", 5000), ("f64", 12000), ("f32", 17000), ("f32", 20000)])
 def test_c2c_any_length_over_a_split_convolution(dtype, n):
     """Lengths whose chirp-z convolution (M >= 2n-1 points) is itself beyond a single kernel."""
