@@ -39,14 +39,15 @@ struct FftKernel {
 // Kernel for a power-of-two length, or nullptr.
 const FftKernel *fft_find(unsigned n, int precision);
 
-// One pass of a long transform n = n1 n2 done in two (f32; N = 256, 512 or 1024 points per column
-// or row): nframe frames of N x ncol points seen as [N][ncol].  mode 1: the N-point transforms of
-// the columns, times W_n^(column . k), columns put back in place (in -> out, same layout);
-// mode 2: the N-point transforms of ncol contiguous rows of `in` ([ncol][N]), stored as columns of
-// `out` ([N][ncol]).  tw = exp(-2 pi i k / N); twa, twb, shift: the two-table form of W_n.
+// One pass of a long transform n = n1 n2 done in two (N = 256, 512 or 1024 points per column or
+// row): nframe frames of N x ncol points.  mode 1: `in` seen as [N][ncol], the N-point transforms
+// of its columns, times W_n^(column . k), left in `out` as tiles [k / 16][column / 16][k % 16][column % 16];
+// mode 2: `in` in those tiles (ncol values of k, N columns), the N-point transforms over the
+// columns, stored as columns of `out` seen as [N][ncol].  tw = exp(-2 pi i k / N); twa, twb, shift:
+// the two-table form of W_n.
 typedef int (*fft_bundle_fn)(const void *in, void *out, const void *tw, size_t nframe, unsigned ncol, const void *twa,
                              const void *twb, unsigned shift, int mode, int backward, int num_cu, hipStream_t s);
-fft_bundle_fn fft_bundle_find(unsigned n);
+fft_bundle_fn fft_bundle_find(unsigned n, int precision);
 
 // Fused overlap-save (f32): blocks of N samples overlapping by nh-1, two real blocks per
 // complex transform, H = FFT_N(taps)/N (device, N complex).  All pointers are device pointers.

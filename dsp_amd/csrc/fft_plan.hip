@@ -403,21 +403,23 @@ int run_pow2(const dspmi::FftKernel *k, const void *in, void *out, const void *t
 //   X[n2 k1 + k2] = sum_a W_n1^(a k1) . W_n^(a k2) . sum_b x[a + n1 b] W_n2^(b k2)
 // as transpose, n1 batched n2-point transforms, transpose with the W_n^(a k2) factors, n2 batched
 // n1-point transforms, transpose.  Frames go through in groups that keep the two work images
-// within `cap` bytes: 128 MiB of plan-owned scratch on the allocating path (kept until the plan is
-// destroyed; the passes are bound by their transposes, not by the group size), or the caller's
-// fixed work space.
+// within `cap` bytes: 128 MiB of plan-owned scratch on the allocating path (256 MiB on the two-pass
+// route; kept until the plan is destroyed), or the caller's fixed work space.
 template <typename T>
 int four_step(dspmi_fft_plan *pl, const C<T> *in, C<T> *out, size_t batch, int backward, hipStream_t s, void *fixed_work,
               size_t fixed_bytes)
 {
     const size_t n = pl->n;
     size_t cap = fixed_work ? fixed_bytes : ((size_t)128 << 20);
-    // Single precision, both factors 256 .. 1024 points (n = 2^16 .. 2^20): two passes, the
-    // transposes folded into the transforms' loads and stores (fft_c2c_bundle_kernel), one work
-    // frame.  DSPMI_FFT_FIVE_PASS=1 keeps the five-pass route below for A/B.
-    if constexpr (sizeof(T) == 4) {
-        const dspmi::fft_bundle_fn pass1 = dspmi::fft_bundle_find(pl->n2), pass2 = dspmi::fft_bundle_find(pl->n1);
+    // Both factors 256 .. 1024 points (n = 2^16 .. 2^20): two passes, the transposes folded into
+    // the transforms' loads and stores (fft_c2c_colreg_kernel), one work frame per frame; groups of
+    // 256 MiB (larger launches count for more than what stays in the last-level cache between
+    // the passes).  DSPMI_FFT_FIVE_PASS=1 keeps the five-pass route below for A/B.
+    {
+        const int prec = sizeof(T) == 8 ? DSPMI_F64 : DSPMI_F32;
+        const dspmi::fft_bundle_fn pass1 = dspmi::fft_bundle_find(pl->n2, prec), pass2 = dspmi::fft_bundle_find(pl->n1, prec);
         if (pass1 && pass2 && !getenv("DSPMI_FFT_FIVE_PASS")) {
+            if (!fixed_work) cap = (size_t)256 << 20;
             const size_t fb = n * sizeof(C<T>);
             if (fixed_work && fb > cap)
                 return dspmi::fail(DSPMI_EINVAL, "fft_exec_c2c_noalloc: one frame of n = %u needs %zu bytes of work space, the static scratch holds %zu",

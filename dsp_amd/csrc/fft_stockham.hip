@@ -2430,126 +2430,161 @@ int launch_c2c_rows(const void *in, void *out, const void *tw, size_t batch, int
 
 // n = n1 n2 points, x[a + n1 b] -> X[n2 k1 + k2]:
 //   X[n2 k1 + k2] = sum_a W_n1^(a k1) . W_n^(a k2) . sum_b x[a + n1 b] W_n2^(b k2)
-// Pass 1 (MODE 1, N = n2, ncol = n1) transforms COLUMNS of the frame seen as [n2][n1]: a workgroup
-// takes FPB adjacent columns, moves them as rows of FPB contiguous points (64 or 128 bytes) through
-// the frames' LDS images -- the transposes of the five-pass scheme, done on chip --, multiplies
-// by W_n^(a k2) and puts the columns back where they came from (in a work frame).  Pass 2
-// (MODE 2, N = n1, ncol = n2) reads FPB adjacent ROWS of that work frame -- contiguous n1-point
-// frames -- and stores their transforms as columns of the output seen as [n1][n2].  Two passes over
-// memory instead of five.  The backward transform conjugates on the way in (pass 1) and on the way
-// out (pass 2).  W_n^e = twa[e >> shift] . twb[e & mask], as in transpose_kernel.
-template <int N, int NT, int R0, int R1, int R2, int R3, int MODE>
-__global__ __launch_bounds__((c2c_block_threads<float, N, NT>())) void fft_c2c_bundle_kernel(const C<float> *in, C<float> *out,
-                                                                             const C<float> *__restrict__ tw, size_t nbundle,
-                                                                             unsigned ncol, const C<float> *__restrict__ twa,
-                                                                             const C<float> *__restrict__ twb, unsigned shift,
-                                                                             int backward)
+// Pass 1 (MODE 1, N = n2, ncol = n1) transforms COLUMNS of the frame seen as [n2][n1] and
+// multiplies by W_n^(a k2); pass 2 (MODE 2, N = n1, ncol = n2) transforms the n1 points of each k2
+// and stores them as a column of the output seen as [n1][n2].  Two passes over memory instead of
+// the five of transposing between batched row transforms.  The backward transform conjugates on
+// the way in (pass 1) and on the way out (pass 2).  W_n^e = twa[e >> shift] . twb[e & mask], as in
+// transpose_kernel.
+//
+// A frame's points are held in registers: N = RA . RB, a workgroup of 16 RB
+// lanes takes 16 adjacent columns, lane (row % RB, column) loads its RA points straight from memory
+// (rows of 16 adjacent columns: 128 contiguous bytes), transforms them, and ONE exchange through
+// LDS -- real parts, then imaginary parts, through an image of 16 N floats -- hands lane
+// (k % RB.., column) the RB points of the second radix.  No transposition through LDS on the way
+// in or out, and 16 N points in flight per workgroup.  Pass 1 leaves its result in tiles
+// [k2 / 16][a / 16][k2 % 16][a % 16], so that a wave stores 512 contiguous bytes and pass 2 reads
+// its 16 rows as one contiguous run of 128 N bytes; pass 2 stores rows of 16 adjacent columns of
+// the output.
+template <typename T, int RA, int RB, int MODE>
+__global__ __launch_bounds__(16 * RB) void fft_c2c_colreg_kernel(const C<T> *in, C<T> *out, const C<T> *__restrict__ tw, unsigned bpf,
+                                                                 unsigned ncol, const C<T> *__restrict__ twa,
+                                                                 const C<T> *__restrict__ twb, unsigned shift, int backward)
 {
-    typedef float T;
-    static_assert(NT <= 64, "a frame inside one wave");
-    constexpr int TW = 2;
-    constexpr int P = N / NT;
-    constexpr int BT = c2c_block_threads<T, N, NT>();
-    constexpr int FPB = BT / NT;
-    constexpr int NPASS = 1 + (R1 > 1) + (R2 > 1) + (R3 > 1);
-    constexpr int RLAST = NPASS == 1 ? R0 : NPASS == 2 ? R1 : NPASS == 3 ? R2 : R3;
-    constexpr int NSLAST = N / RLAST;
-    static_assert(N * FPB == P * BT, "every lane moves P points of the bundle");
-
+    // RA >= RB: lane (kq, column) of the second radix takes M = RA / RB transforms, k % RA = kq + RB m;
+    // RA < RB: one transform in the lanes with kq < RA, the others only keep the barriers company
+    constexpr int N = RA * RB, M = RA >= RB ? RA / RB : 1, P = RA >= RB ? RA : RB, SB = RA + 1,
+                  SC = RB * SB + (34 - (RB * SB) % 32) % 32;
+    static_assert((RA >= RB ? M * RB == RA : RB % RA == 0) && RB % 16 == 0, "whole transforms per lane, whole tiles of 16 rows");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const unsigned slot = threadIdx.x / NT, tl = threadIdx.x % NT;
-    C<T> *img0 = reinterpret_cast<C<T> *>(smem_raw);
-    C<T> *lds = img0 + (size_t)slot * padded_len(N);
-    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
-    setup_lds_twiddles<T, N, BT, FPB, R0, R1, R2, R3>(smem_raw, tw, tw1, tw2, tw3);
+    T *cimg = reinterpret_cast<T *>(smem_raw);
+    const unsigned tid = threadIdx.x;
+    const size_t F = blockIdx.x / bpf;
+    const unsigned cb = (unsigned)(blockIdx.x - F * bpf);  // the bundle of 16 columns within the frame
+    const size_t base = F * (size_t)N * ncol;
     const T sgn = backward ? T(-1) : T(1);
-    const unsigned bpf = ncol / FPB;  // bundles per frame
 
-    for (size_t g = blockIdx.x; g < nbundle; g += gridDim.x) {
-        const size_t F = g / bpf;
-        const unsigned c0 = (unsigned)(g - F * bpf) * FPB;
-        const size_t base = F * (size_t)N * ncol;
-        C<T> v[P];
-        if constexpr (MODE == 1) {
+    C<T> v[P];
+    unsigned lo, col;
+    if constexpr (MODE == 1) {
+        col = tid & 15;
+        lo = tid >> 4;
+        const C<T> *src = in + base + (size_t)lo * ncol + cb * 16 + col;
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                const unsigned e = threadIdx.x + BT * i, row = e / FPB, c = e % FPB;
-                img0[c * padded_len(N) + pad(row)] = nt_load(&in[base + (size_t)row * ncol + c0 + c]);
-            }
+        for (int j = 0; j < RA; j++) {
+            C<T> q = nt_load(src + (size_t)(RB * j) * ncol);
+            q.im *= sgn;
+            v[j] = q;
+        }
+    } else {
+        col = (tid >> 4) & 15;
+        lo = (tid & 15) + 16 * (tid >> 8);
+        const C<T> *src = in + base + (size_t)cb * (16 * N) + tid;
+#pragma unroll
+        for (int j = 0; j < RA; j++) v[j] = src[RB * 16 * j];
+    }
+    dft_reg<RA, 1>(v);
+    {
+        // W_N^(lo ka) for ka = 1, 2, 3 and 4, 8, ..; the others as two factors
+        C<T> l3[3], h4[RA / 4 - 1];
+#pragma unroll
+        for (int b = 1; b < 4; b++) l3[b - 1] = tw[lo * b];
+#pragma unroll
+        for (int a = 1; a < RA / 4; a++) h4[a - 1] = tw[lo * 4 * a];
+#pragma unroll
+        for (int ka = 1; ka < RA; ka++) {
+            if (ka / 4) v[ka] = cmul(v[ka], h4[ka / 4 - 1]);
+            if (ka % 4) v[ka] = cmul(v[ka], l3[ka % 4 - 1]);
+        }
+    }
+    const unsigned kq = tid >> 4, colr = tid & 15;
+    const bool active = RA >= RB || kq < RA;
+    {
+        T *wp = cimg + col * SC + lo * SB;
+        const T *rp = cimg + colr * SC + kq;
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            if (comp) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RA; j++) wp[j] = comp ? v[j].im : v[j].re;
             __syncthreads();
+            if (active)
 #pragma unroll
-            for (int b = 0; b < P / R0; b++)
+                for (int m = 0; m < M; m++)
 #pragma unroll
-                for (int r = 0; r < R0; r++) {
-                    C<T> q = lds[pad(tl + NT * b + r * (N / R0))];
-                    q.im *= sgn;
-                    v[b * R0 + r] = q;
-                }
-            frame_sync<NT>();  // the frame's own lanes have read it before its passes write it
-        } else {
-            const C<T> *src = in + base + (size_t)(c0 + slot) * N;
-#pragma unroll
-            for (int b = 0; b < P / R0; b++)
-#pragma unroll
-                for (int r = 0; r < R0; r++) v[b * R0 + r] = nt_load(&src[tl + NT * b + r * (N / R0)]);
+                    for (int j = 0; j < RB; j++) {
+                        const T q = rp[j * SB + RB * m];
+                        if (comp) v[m * RB + j].im = q;
+                        else v[m * RB + j].re = q;
+                    }
         }
-        run_passes<T, N, NT, R0, R1, R2, R3, TW>(v, lds, tw1, tw2, tw3, tw, tl);
-        frame_sync<NT>();
-        // results to their natural places in the frame's image
+    }
+    if (!active) return;  // no barrier from here on
 #pragma unroll
-        for (int b = 0; b < P / RLAST; b++)
+    for (int m = 0; m < M; m++) dft_reg<RB, 1>(&v[m * RB]);
+    // v[m RB + kb] = X[kq + RB m + RA kb] of column colr
+    if constexpr (MODE == 1) {
+        const unsigned a = cb * 16 + colr, mask = (1u << shift) - 1;
+        auto W = [&](unsigned e) { return cmul(twa[e >> shift], twb[e & mask]); };  // W_n^e, e < n
+        C<T> l[4], h[RB / 4];
+        const unsigned gstep = a * RA;
 #pragma unroll
-            for (int r = 0; r < RLAST; r++) {
-                const unsigned k = tl + NT * b + r * NSLAST;
-                C<T> q = v[b * RLAST + r];
-                if constexpr (MODE == 1) {
-                    const unsigned e = (c0 + slot) * k;  // < n
-                    q = cmul(q, cmul(twa[e >> shift], twb[e & ((1u << shift) - 1)]));
-                } else {
-                    q.im *= sgn;
-                }
-                lds[pad(k)] = q;
+        for (int i = 1; i < 4; i++) l[i] = W(gstep * i);
+#pragma unroll
+        for (int i = 1; i < RB / 4; i++) h[i] = W(gstep * 4 * i);
+        C<T> *dst = out + base + (size_t)cb * 256 + colr;
+        const size_t tile_pitch = (size_t)ncol * 16;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const C<T> b0 = W(a * (kq + RB * m));
+            const C<T> lb[4] = {b0, cmul(b0, l[1]), cmul(b0, l[2]), cmul(b0, l[3])};
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) {
+                C<T> f = lb[kb % 4];
+                if (kb / 4) f = cmul(f, h[kb / 4]);
+                const unsigned k = kq + RB * m + RA * kb;
+                dst[(size_t)(k >> 4) * tile_pitch + (k & 15) * 16] = cmul(v[m * RB + kb], f);
             }
-        __syncthreads();
-        // ... and out as rows of FPB adjacent columns
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            const unsigned e = threadIdx.x + BT * i, row = e / FPB, c = e % FPB;
-            nt_store(img0[c * padded_len(N) + pad(row)], &out[base + (size_t)row * ncol + c0 + c]);
         }
-        __syncthreads();  // the images are free for the next bundle
+    } else {
+        C<T> *dst = out + base + cb * 16 + colr;
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int kb = 0; kb < RB; kb++) {
+                const unsigned k = kq + RB * m + RA * kb;
+                C<T> q = v[m * RB + kb];
+                q.im *= sgn;
+                nt_store(q, dst + (size_t)k * ncol);
+            }
     }
 }
 
-template <int N, int NT, int R0, int R1, int R2, int R3>
-int launch_c2c_bundle(const void *in, void *out, const void *tw, size_t nframe, unsigned ncol, const void *twa, const void *twb,
+template <typename T, int RA, int RB>
+int launch_c2c_colreg(const void *in, void *out, const void *tw, size_t nframe, unsigned ncol, const void *twa, const void *twb,
                       unsigned shift, int mode, int backward, int num_cu, hipStream_t s)
 {
-    constexpr int BT = c2c_block_threads<float, N, NT>();
-    constexpr int FPB = BT / NT;
-    constexpr size_t lds = ((size_t)FPB * padded_len(N) + lds_twiddle_entries(2, R0, R1, R2, R3, N)) * sizeof(C<float>);
-    auto k1 = fft_c2c_bundle_kernel<N, NT, R0, R1, R2, R3, 1>;
-    auto k2 = fft_c2c_bundle_kernel<N, NT, R0, R1, R2, R3, 2>;
+    constexpr int SB = RA + 1, SC = RB * SB + (34 - (RB * SB) % 32) % 32;
+    constexpr size_t lds = (size_t)16 * SC * sizeof(T);
+    auto k1 = fft_c2c_colreg_kernel<T, RA, RB, 1>;
+    auto k2 = fft_c2c_colreg_kernel<T, RA, RB, 2>;
     static dspmi::PerDeviceOnce attr;
     if (attr.pending()) {
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.mark();
     }
-    if (ncol % FPB) return dspmi::fail(DSPMI_EINVAL, "fft: %u columns do not divide into bundles of %d", ncol, FPB);
-    const size_t nbundle = nframe * (ncol / FPB);
+    if (ncol % 16) return dspmi::fail(DSPMI_EINVAL, "fft: %u columns do not divide into bundles of 16", ncol);
+    const size_t nbundle = nframe * (ncol / 16);
     if (nbundle == 0) return DSPMI_OK;
-    const size_t grid = nbundle < 0x7fffffffu ? nbundle : 0x7fffffffu;  // one bundle per workgroup: the dispatcher keeps the chip filled
-    hipLaunchKernelGGL(mode == 1 ? k1 : k2, dim3((unsigned)grid), dim3(BT), lds, s, static_cast<const C<float> *>(in),
-                       static_cast<C<float> *>(out), static_cast<const C<float> *>(tw), nbundle, ncol,
-                       static_cast<const C<float> *>(twa), static_cast<const C<float> *>(twb), shift, backward);
+    if (nbundle > 0x7fffffffu) return dspmi::fail(DSPMI_EINVAL, "fft: %zu column bundles in one launch", nbundle);
+    (void)num_cu;
+    hipLaunchKernelGGL(mode == 1 ? k1 : k2, dim3((unsigned)nbundle), dim3(16 * RB), lds, s, static_cast<const C<T> *>(in),
+                       static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), ncol / 16, ncol, static_cast<const C<T> *>(twa),
+                       static_cast<const C<T> *>(twb), shift, backward);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
-
-// ---------------------------------------------------------------------------
-// launchers and the kernel table
-// ---------------------------------------------------------------------------
 
 template <typename T, int N, int NT, int R0, int R1, int R2, int R3, int TW, bool PREFETCH, int NTMEM = 0>
 int launch_c2c(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
@@ -2779,12 +2814,19 @@ int fir_spectrum_launch(const FirSpectrumLaunch &a, hipStream_t s)
 
 const FftKernel *fft_find(unsigned n, int precision) { return find_entry(n, precision); }
 
-fft_bundle_fn fft_bundle_find(unsigned n)
+fft_bundle_fn fft_bundle_find(unsigned n, int precision)
 {
+    if (precision == DSPMI_F64) switch (n) {
+        case 128: return launch_c2c_colreg<double, 8, 16>;
+        case 256: return launch_c2c_colreg<double, 16, 16>;
+        case 512: return launch_c2c_colreg<double, 32, 16>;
+        case 1024: return launch_c2c_colreg<double, 32, 32>;
+        default: return nullptr;
+        }
     switch (n) {
-    case 256: return launch_c2c_bundle<256, 16, 16, 16, 1, 1>;
-    case 512: return launch_c2c_bundle<512, 32, 16, 16, 2, 1>;
-    case 1024: return launch_c2c_bundle<1024, 64, 16, 16, 4, 1>;
+    case 256: return launch_c2c_colreg<float, 16, 16>;
+    case 512: return launch_c2c_colreg<float, 32, 16>;
+    case 1024: return launch_c2c_colreg<float, 32, 32>;
     }
     return nullptr;
 }

@@ -371,24 +371,33 @@ def test_c2c_long_powers_of_two(dtype, n, batch):
     assert rel_l2(buf.cpu().numpy() / n, z) <= 4 * tol
 
 
-@pytest.mark.parametrize("n,batch", [(1 << 16, 5), (1 << 17, 3), (1 << 18, 2), (1 << 19, 2), (1 << 20, 3), (1 << 21, 1)])
-def test_c2c_long_transforms_in_two_passes(n, batch, monkeypatch):
-    """Single precision, 2^16 .. 2^20 points: two passes with the transposes folded into the
-    transforms' loads and stores; 2^21 and beyond, and DSPMI_FFT_FIVE_PASS=1, take the five-pass
-    route.  Both against the oracle per frame, forward and backward, and against each other."""
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n,batch", [(1 << 14, 9), (1 << 15, 4), (1 << 16, 5), (1 << 17, 3), (1 << 18, 2), (1 << 19, 2), (1 << 20, 3),
+                                     (1 << 21, 1)])
+def test_c2c_long_transforms_in_two_passes(n, batch, dtype, monkeypatch):
+    """2^16 .. 2^20 points (from 2^14 in double precision, where one kernel holds 8192 points at
+    most): two passes over memory, the transposes folded into the transforms' loads and stores;
+    2^21 points and beyond, and DSPMI_FFT_FIVE_PASS=1, take the five-pass route.  Both
+    against the oracle on one frame, forward and backward, and against each other on every frame."""
+    ct, tol, same = (np.complex64, TOL_FFT, 1e-6) if dtype == "f32" else (np.complex128, TOL_F64, 1e-14)
     rng = np.random.default_rng(n)
-    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
+    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(ct)
     zd = torch.from_numpy(z).cuda()
-    plan = dsp_amd.FftPlan(n, "f32")
+    plan = dsp_amd.FftPlan(n, dtype)
     for sign in (dsp_amd.FORWARD, dsp_amd.BACKWARD):
         monkeypatch.delenv("DSPMI_FFT_FIVE_PASS", raising=False)
         two = plan.c2c(zd, sign).cpu().numpy()
         monkeypatch.setenv("DSPMI_FFT_FIVE_PASS", "1")
         five = plan.c2c(zd, sign).cpu().numpy()
         want = oracle.dft(z[batch - 1].astype(np.complex128), sign, "radix2")
-        assert rel_l2(two[batch - 1], want) <= TOL_FFT and rel_l2(five[batch - 1], want) <= TOL_FFT
+        assert rel_l2(two[batch - 1], want) <= tol and rel_l2(five[batch - 1], want) <= tol
         for f in range(batch):
-            assert rel_l2(two[f], five[f].astype(np.complex128)) <= 1e-6, (n, sign, f)
+            assert rel_l2(two[f], five[f].astype(np.complex128)) <= same, (n, sign, f)
+    # in place, and a batch that does not fill the last group of work frames
+    monkeypatch.delenv("DSPMI_FFT_FIVE_PASS", raising=False)
+    buf = zd.clone()
+    plan.c2c(buf, out=buf)
+    assert torch.equal(torch.view_as_real(buf), torch.view_as_real(plan.c2c(zd)))
 
 
 @pytest.mark.parametrize("dtype,n", [("f64", 5000), ("f64", 12000), ("f32", 17000), ("f32", 20000)])
