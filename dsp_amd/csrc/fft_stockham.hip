@@ -2186,241 +2186,131 @@ const BluesteinEntry kBluesteinF32[] = {
 };
 
 // ---------------------------------------------------------------------------
-// c2c, 16384 points: radix-16 stage across the workgroup, one 1024-point row per wave
+// c2c with the whole frame in registers: 1024 .. 32768 points
 // ---------------------------------------------------------------------------
 
-// The factorisation of ols_wave_kernel (n = n2 + 1024 n1, k = k1 + 16 k2) for the plain complex
-// transform: lane n2 loads x[n2 + 1024 n1], does the radix-16 sum and the W_N^(n2 k1) factors
-// (read from the plan's N-entry table, which also serves the rows' twiddles at stride 16), one
-// exchange hands wave k1 its row, the row's 1024-point transform runs inside the wave, and a
-// second exchange puts X[k1 + 16 k2] back into natural order for contiguous stores.  Two
-// workgroup-wide exchanges instead of three, and -- because a frame is only 16 points per lane --
-// the next frame is requested before the rows are transformed, so HBM works while the CU
-// computes (one 139 KB frame image fits a CU: without that, loading, computing and storing
-// would take turns).
-template <int NTMEM>
-__global__ __launch_bounds__(1024) void fft_c2c_rows_kernel(const C<float> *in, C<float> *out, const C<float> *__restrict__ tw,
-                                                            size_t batch, int flags)
+// A whole frame in the registers of one workgroup: N = P . P . RC points, L = P RC lanes with P
+// points each.  n = n0 + L n1 (n1 < P), n0 = m0 + RC m1; k = k1 + P q1 + P^2 q0:
+//   X[k] = sum_m0 W_RC^(m0 q0) . W_L^(m0 q1) sum_m1 W_P^(m1 q1) . W_N^(n0 k1) sum_n1 W_P^(n1 k1) x[n]
+// Lane n0 loads x[n0 + L n1] straight into registers (a wave reads 512 contiguous bytes) and
+// transforms over n1; an exchange through LDS -- real parts, then imaginary parts, through an image
+// of about N scalars -- hands lane (k1, m0) its P values of m1; after the second radix a second
+// exchange hands lane t the RC values of m0 for k1 + P q1 = t + L i, whose transforms
+// X[t + L i + P^2 q0] go out in natural order (contiguous over the lanes again).  Both images are
+// read and written without bank conflicts (rows of L + 32 / P scalars in the first, unit stride
+// over k1 and padded planes in the second).  Half the LDS of a frame image of complex points, so
+// two workgroups fit a CU at 16384 points in single precision and one loads while the other
+// computes; 32768 points fit at all.
+template <typename T, int P, int RC, int NTMEM>
+__global__ __launch_bounds__(P * RC) void fft_c2c_reg3_kernel(const C<T> *in, C<T> *out, const C<T> *__restrict__ tw, size_t batch,
+                                                              int flags)
 {
-    typedef float T;
-    constexpr int K1 = 16, NS = 1024, N = K1 * NS;
-    constexpr int R0 = 16, R1 = 4, R2 = 16;
-    constexpr int OROW = NS + 2;  // row pitch of the output image: lanes 16 rows apart hit different banks
-
+    constexpr int L = P * RC, N = P * L, TC = P / RC, ROW = L + 32 / P, PLANE = P * P + (P < 32 ? 16 : 0);
+    static_assert(RC * TC == P && (P == 16 || P == 32), "whole last-radix transforms per lane");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const unsigned tl = threadIdx.x, lane = tl & 63, wave = tl >> 6;
-    C<T> *img = reinterpret_cast<C<T> *>(smem_raw);
-    C<T> *wreg = img + (size_t)wave * padded_len(NS);
-    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
-    setup_lds_twiddles<T, NS, 1024, K1, R0, R1, R2, 1, K1>(smem_raw, tw, tw1, tw2, tw3);
-    const bool backward = (flags & kFftBackward) != 0;  // swap . forward . swap
+    T *img = reinterpret_cast<T *>(smem_raw);
+    const unsigned t = threadIdx.x, k1 = t % P, m0 = t / P;
+    const T sgn = (flags & kFftBackward) ? T(-1) : T(1);  // conjugate . forward . conjugate
+    const size_t f = blockIdx.x;
+    if (f >= batch) return;
 
-    auto load_frame = [&](C<T> (&v)[K1], size_t f) {
-        const C<T> *src = in + f * N + tl;
+    C<T> v[P];
+    {
+        const C<T> *src = in + f * N + t;
 #pragma unroll
-        for (int n1 = 0; n1 < K1; n1++) {
-            const C<T> q = (NTMEM & 1) ? nt_load(src + NS * n1) : src[NS * n1];
-            v[n1] = backward ? C<T>{q.im, q.re} : q;
+        for (int j = 0; j < P; j++) {
+            C<T> q = (NTMEM & 1) ? nt_load(src + L * j) : src[L * j];
+            q.im *= sgn;
+            v[j] = q;
+        }
+    }
+    // two factors for every W^(g k), k = 1 .. P - 1: k = 4 a + b
+    auto twiddle = [&](unsigned g) {
+        C<T> l3[3], h4[P / 4 - 1];
+#pragma unroll
+        for (int b = 1; b < 4; b++) l3[b - 1] = tw[g * b];
+#pragma unroll
+        for (int a = 1; a < P / 4; a++) h4[a - 1] = tw[g * 4 * a];
+#pragma unroll
+        for (int k = 1; k < P; k++) {
+            if (k / 4) v[k] = cmul(v[k], h4[k / 4 - 1]);
+            if (k % 4) v[k] = cmul(v[k], l3[k % 4 - 1]);
         }
     };
-
-    size_t f = blockIdx.x;
-    if (f >= batch) return;
-    C<T> v[K1];
-    load_frame(v, f);
-    for (; f < batch; f += gridDim.x) {
-        unsigned tt = tl;
-        asm volatile("" : "+v"(tt));  // the stage factors' addresses are the same for every frame
-        // stage factors W^(k1 n2) for k1 = 1, 2, 3 and 4, 8, 12; the others as two factors
-        C<T> lo[3], hi[3];
-#pragma unroll
-        for (int b = 1; b < 4; b++) lo[b - 1] = tw[tt * b];
-#pragma unroll
-        for (int a = 1; a < 4; a++) hi[a - 1] = tw[tt * 4 * a];
-        dft_reg<K1, 1>(v);
-#pragma unroll
-        for (int k1 = 1; k1 < K1; k1++) {
-            if (k1 / 4) v[k1] = cmul(v[k1], hi[k1 / 4 - 1]);
-            if (k1 % 4) v[k1] = cmul(v[k1], lo[k1 % 4 - 1]);
-        }
-#pragma unroll
-        for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = v[k1];
-        __syncthreads();
-        C<T> u[16];
-#pragma unroll
-        for (int r = 0; r < 16; r++) u[r] = img[NS * wave + lane + 64 * r];
-        __syncthreads();
-        // the next frame is on its way while this one's rows are transformed
-        const size_t fn = f + gridDim.x;
-        if (fn < batch) load_frame(v, fn);
-        unsigned la = lane;
-        asm volatile("" : "+v"(la));
-        row_passes_1024(u, wreg, tw1, tw2, la);
-        __syncthreads();  // the waves' regions alias the image
-        C<T> *oimg = img + (size_t)OROW * wave + lane;
-#pragma unroll
-        for (int r = 0; r < 16; r++) oimg[64 * r] = u[r];  // X[wave + 16 k2] at [wave][k2], k2 = lane + 64 r
-        __syncthreads();
-        {
-            unsigned to = tl;
-            asm volatile("" : "+v"(to));
-            // natural order: k = to + 1024 j = k1 + 16 k2 with k1 = to % 16, k2 = to / 16 + 64 j
-            const C<T> *src = img + (size_t)OROW * (to & 15) + (to >> 4);
-            C<T> *dst = out + f * N + to;
-#pragma unroll
-            for (int j = 0; j < K1; j++) {
-                C<T> q = src[64 * j];
-                if (backward) q = C<T>{q.im, q.re};
-                if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + NS * j);
-                else dst[NS * j] = q;
-            }
-        }
-        __syncthreads();  // the image is free for the next frame's exchange
-    }
-}
-
-// The same for 32768 points: 32 points per lane (no room to request the next frame early), two
-// rows per wave, and -- the frame being 256 KB -- both exchanges move the real parts, then the
-// imaginary parts, through a 32768-float image, as in ols_wave_kernel.
-template <int NTMEM>
-__global__ __launch_bounds__(1024) void fft_c2c_rows32_kernel(const C<float> *in, C<float> *out, const C<float> *__restrict__ tw,
-                                                              size_t batch, int flags)
-{
-    typedef float T;
-    constexpr int K1 = 32, NS = 1024, N = K1 * NS, SPW = 2;
-    constexpr int R0 = 16, R1 = 4, R2 = 16;
-    constexpr int OROW = NS + 1;  // row pitch of the output image (floats): 32 rows read at once fall on 32 banks
-
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const unsigned tl = threadIdx.x, lane = tl & 63, wave = tl >> 6;
-    float *img = reinterpret_cast<float *>(smem_raw);
-    C<T> *wreg = reinterpret_cast<C<T> *>(smem_raw) + (size_t)wave * padded_len(NS);
-    const C<T> *tw1 = nullptr, *tw2 = nullptr, *tw3 = nullptr;
-    setup_lds_twiddles<T, NS, 1024, 16, R0, R1, R2, 1, K1>(smem_raw, tw, tw1, tw2, tw3);
-    const bool backward = (flags & kFftBackward) != 0;  // swap . forward . swap
-
-    for (size_t f = blockIdx.x; f < batch; f += gridDim.x) {
-        unsigned tt = tl;
-        asm volatile("" : "+v"(tt));
-        C<T> v[K1];
-        {
-            const C<T> *src = in + f * N + tt;
-#pragma unroll
-            for (int n1 = 0; n1 < K1; n1++) {
-                const C<T> q = (NTMEM & 1) ? nt_load(src + NS * n1) : src[NS * n1];
-                v[n1] = backward ? C<T>{q.im, q.re} : q;
-            }
-        }
-        // stage factors W^(k1 n2) for k1 = 1, 2, 3 and 4, 8, .. 28; the others as two factors
-        C<T> lo[3], hi[7];
-#pragma unroll
-        for (int b = 1; b < 4; b++) lo[b - 1] = tw[tt * b];
-#pragma unroll
-        for (int a = 1; a < 8; a++) hi[a - 1] = tw[tt * 4 * a];
-        dft_reg<K1, 1>(v);
-#pragma unroll
-        for (int k1 = 1; k1 < K1; k1++) {
-            if (k1 / 4) v[k1] = cmul(v[k1], hi[k1 / 4 - 1]);
-            if (k1 % 4) v[k1] = cmul(v[k1], lo[k1 % 4 - 1]);
-        }
-        C<T> u[SPW][16];
-#pragma unroll
-        for (int comp = 0; comp < 2; comp++) {
-#pragma unroll
-            for (int k1 = 0; k1 < K1; k1++) img[NS * k1 + tl] = comp ? v[k1].im : v[k1].re;
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < SPW; s++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float q = img[NS * (wave * SPW + s) + lane + 64 * r];
-                    if (comp) u[s][r].im = q;
-                    else u[s][r].re = q;
-                }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int s = 0; s < SPW; s++) {
-            unsigned la = lane;
-            asm volatile("" : "+v"(la));
-            row_passes_1024(u[s], wreg, tw1, tw2, la);
-        }
-        __syncthreads();  // the waves' regions alias the image
-        unsigned to = tl;
-        asm volatile("" : "+v"(to));
-#pragma unroll
-        for (int comp = 0; comp < 2; comp++) {
-            // X[k1 + 32 k2] of row k1 at [k1][k2]
-#pragma unroll
-            for (int s = 0; s < SPW; s++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) img[OROW * (wave * SPW + s) + lane + 64 * r] = comp ? u[s][r].im : u[s][r].re;
-            __syncthreads();
-            // natural order: k = to + 1024 j = k1 + 32 k2 with k1 = to % 32, k2 = to / 32 + 32 j
-            const float *src = img + OROW * (to & 31) + (to >> 5);
-#pragma unroll
-            for (int j = 0; j < K1; j++) {
-                if (comp) v[j].im = src[32 * j];
-                else v[j].re = src[32 * j];
-            }
-            __syncthreads();
-        }
-        C<T> *dst = out + f * N + to;
-#pragma unroll
-        for (int j = 0; j < K1; j++) {
-            const C<T> q = backward ? C<T>{v[j].im, v[j].re} : v[j];
-            if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + NS * j);
-            else dst[NS * j] = q;
-        }
-    }
-}
-
-template <int NTMEM>
-int launch_c2c_rows32(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
-{
-    constexpr int NS = 1024, K1 = 32;
-    constexpr size_t regions = (size_t)16 * padded_len(NS) * sizeof(C<float>);
-    static_assert((size_t)K1 * (NS + 1) * sizeof(float) <= regions, "the images alias the waves' regions");
-    constexpr size_t lds = regions + lds_twiddle_entries(2, 16, 4, 16, 1) * sizeof(C<float>);
-    auto kern = fft_c2c_rows32_kernel<NTMEM>;
-    static dspmi::PerDeviceOnce attr;
-    if (attr.pending()) {
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr.mark();
-    }
-    if (batch == 0) return DSPMI_OK;
-    const size_t grid = batch < (size_t)num_cu ? batch : (size_t)num_cu;  // one workgroup fits a CU
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, static_cast<const C<float> *>(in), static_cast<C<float> *>(out),
-                       static_cast<const C<float> *>(tw), batch, backward ? kFftBackward : 0);
-    DSPMI_HIP(hipGetLastError());
-    return DSPMI_OK;
-}
-
-template <int NTMEM>
-int launch_c2c_rows(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
-{
-    constexpr int NS = 1024, K1 = 16;
-    constexpr size_t regions = (size_t)K1 * padded_len(NS) * sizeof(C<float>);
-    static_assert((size_t)K1 * (NS + 2) * sizeof(C<float>) <= regions, "the output image aliases the waves' regions");
-    constexpr size_t lds = regions + lds_twiddle_entries(2, 16, 4, 16, 1) * sizeof(C<float>);
-    auto kern = fft_c2c_rows_kernel<NTMEM>;
-    static dspmi::PerDeviceOnce attr;
-    if (attr.pending()) {
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr.mark();
-    }
-    if (batch == 0) return DSPMI_OK;
-    size_t grid = batch < (size_t)num_cu ? batch : (size_t)num_cu;  // one workgroup fits a CU
+    dft_reg<P, 1>(v);  // over n1 -> k1
+    twiddle(t);        // W_N^(n0 k1)
     {
-        const char *env = getenv("DSPMI_FFT_ITERS");  // experiment: frames per workgroup
-        if (env && atof(env) > 0) {
-            const size_t g = (size_t)((double)batch / atof(env) + 0.999);
-            if (g > grid) grid = g > batch ? batch : g;
+        T *wp = img + t;                      // [k1][n0]
+        const T *rp = img + k1 * ROW + m0;    // n0 = m0 + RC m1
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            if (comp) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < P; j++) wp[j * ROW] = comp ? v[j].im : v[j].re;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < P; j++) {
+                const T q = rp[RC * j];
+                if (comp) v[j].im = q;
+                else v[j].re = q;
+            }
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, s, static_cast<const C<float> *>(in), static_cast<C<float> *>(out),
-                       static_cast<const C<float> *>(tw), batch, backward ? kFftBackward : 0);
-    DSPMI_HIP(hipGetLastError());
+    dft_reg<P, 1>(v);   // over m1 -> q1
+    twiddle(P * m0);    // W_L^(m0 q1)
+    {
+        T *wp = img + k1 + PLANE * m0;  // [m0][q1][k1]
+        const T *rp = img + t;          // k1 + P q1 = t + L i
+#pragma unroll
+        for (int comp = 0; comp < 2; comp++) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < P; j++) wp[P * j] = comp ? v[j].im : v[j].re;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TC; i++)
+#pragma unroll
+                for (int j = 0; j < RC; j++) {
+                    const T q = rp[L * i + PLANE * j];
+                    if (comp) v[i * RC + j].im = q;
+                    else v[i * RC + j].re = q;
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TC; i++) dft_reg<RC, 1>(&v[i * RC]);  // over m0 -> q0
+    C<T> *dst = out + f * N + t;
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+#pragma unroll
+        for (int q0 = 0; q0 < RC; q0++) {
+            C<T> q = v[i * RC + q0];
+            q.im *= sgn;
+            if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + L * i + P * P * q0);
+            else dst[L * i + P * P * q0] = q;
+        }
+}
+
+template <typename T, int P, int RC, int NTMEM>
+int launch_c2c_reg3(const void *in, void *out, const void *tw, size_t batch, int backward, int num_cu, hipStream_t s)
+{
+    constexpr int L = P * RC, N = P * L, ROW = L + 32 / P, PLANE = P * P + (P < 32 ? 16 : 0);
+    constexpr size_t lds = (size_t)(P * ROW > RC * PLANE ? P * ROW : RC * PLANE) * sizeof(T);
+    auto kern = fft_c2c_reg3_kernel<T, P, RC, NTMEM>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    (void)num_cu;
+    // one frame per workgroup: the dispatcher keeps every CU filled
+    for (size_t done = 0; done < batch;) {
+        const size_t g = batch - done < 0x40000000u ? batch - done : 0x40000000u;
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(L), lds, s, static_cast<const C<T> *>(in) + done * N,
+                           static_cast<C<T> *>(out) + done * N, static_cast<const C<T> *>(tw), g, backward ? kFftBackward : 0);
+        DSPMI_HIP(hipGetLastError());
+        done += g;
+    }
     return DSPMI_OK;
 }
 
@@ -2725,14 +2615,25 @@ typedef dspmi::FftKernel FftEntry;
     {N, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, launch_c2c<double, N, NT, A, B, C_, D, 0, false, 0>, \
      "fft_f64_n" #N "_r" #A "x" #B "x" #C_ "x" #D, nullptr, nullptr}
 
+// the whole frame in registers (fft_c2c_reg3_kernel): the long single-precision frames, and double
+// precision from 1024 points on (4.4-4.8 -> 5.7-5.8 TB/s; 8192 points 3.2 -> 5.7)
+#define REG3(T, TN, P, RC) \
+    {P * P * RC, launch_c2c_reg3<T, P, RC, 0>, launch_c2c_reg3<T, P, RC, 3>, "fft_" TN "_n" REG3_STR(P, RC) "_reg" #P "x" #P "x" #RC, nullptr, nullptr}
+#define REG3_STR(P, RC) REG3_N_##P##_##RC
+#define REG3_N_16_4 "1024"
+#define REG3_N_16_8 "2048"
+#define REG3_N_16_16 "4096"
+#define REG3_N_32_8 "8192"
+#define REG3_N_32_16 "16384"
+#define REG3_N_32_32 "32768"
+
 const FftEntry kF32[] = {
     F32S(2, 1, 2, 1, 1, 1),         F32S(4, 1, 4, 1, 1, 1),         F32S(8, 1, 8, 1, 1, 1),
     F32S(16, 1, 16, 1, 1, 1),       F32S(32, 2, 16, 2, 1, 1),       F32S(64, 4, 16, 4, 1, 1),
     F32(128, 8, 16, 8, 1, 1),       F32(256, 16, 16, 16, 1, 1),     F32(512, 32, 16, 16, 2, 1),
     F32(1024, 64, 16, 16, 4, 1),    F32T(2048, 128, 16, 16, 8, 1, 2), F32T(4096, 256, 16, 16, 16, 1, 2),
     F32T(8192, 512, 16, 16, 16, 2, 3),
-    {16384, launch_c2c_rows<0>, launch_c2c_rows<3>, "fft_f32_n16384_r16_rows1024", nullptr, nullptr},
-    {32768, launch_c2c_rows32<0>, launch_c2c_rows32<3>, "fft_f32_n32768_r32_rows1024", nullptr, nullptr},
+    REG3(float, "f32", 32, 16),     REG3(float, "f32", 32, 32),
 };
 // the 16384-point transform as one frame image exchanged three times (A/B: DSPMI_FFT_VARIANT=1 at N = 16384)
 const FftEntry kF32Alt16384 = {16384, launch_c2c<float, 16384, 1024, 16, 16, 16, 4, 3, false, 0>,
@@ -2741,6 +2642,11 @@ const FftEntry kF64[] = {
     F64(2, 1, 2, 1, 1, 1),        F64(4, 1, 4, 1, 1, 1),         F64(8, 1, 8, 1, 1, 1),
     F64(16, 2, 8, 2, 1, 1),       F64(32, 4, 8, 4, 1, 1),        F64(64, 8, 8, 8, 1, 1),
     F64(128, 16, 8, 8, 2, 1),     F64(256, 32, 8, 8, 4, 1),      F64(512, 64, 8, 8, 8, 1),
+    REG3(double, "f64", 16, 4),   REG3(double, "f64", 16, 8),    REG3(double, "f64", 16, 16),
+    REG3(double, "f64", 32, 8),   REG3(double, "f64", 32, 16),
+};
+// the same lengths with the frame in an LDS image (A/B: DSPMI_FFT_VARIANT=1)
+const FftEntry kF64Alt[] = {
     F64(1024, 128, 8, 8, 8, 2),   F64(2048, 256, 8, 8, 8, 4),    F64(4096, 512, 8, 8, 8, 8),
     F64(8192, 512, 16, 16, 16, 2),
 };
@@ -2764,6 +2670,12 @@ const FftEntry *find_entry(unsigned n, int precision)
     if (n == 16384 && precision == DSPMI_F32) {
         const char *env = getenv("DSPMI_FFT_VARIANT");
         if (env && atoi(env) == 1) return &kF32Alt16384;
+    }
+    if (precision == DSPMI_F64) {
+        const char *env = getenv("DSPMI_FFT_VARIANT");
+        if (env && atoi(env) == 1)
+            for (const FftEntry &e : kF64Alt)
+                if (e.n == n) return &e;
     }
     const FftEntry *tab = precision == DSPMI_F64 ? kF64 : kF32;
     const size_t cnt = precision == DSPMI_F64 ? sizeof(kF64) / sizeof(kF64[0]) : sizeof(kF32) / sizeof(kF32[0]);

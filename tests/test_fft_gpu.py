@@ -350,7 +350,7 @@ def test_batched_real_transforms_any_length(dtype, n, batch):
 # ---- lengths beyond the longest single-workgroup kernel: n = n1 * n2 in two batched passes ----
 
 @pytest.mark.parametrize("dtype,n,batch", [("f32", 65536, 3), ("f32", 1 << 17, 2), ("f32", 1 << 20, 1),
-                                           ("f64", 16384, 3), ("f64", 65536, 2), ("f64", 1 << 20, 1)])
+                                           ("f64", 32768, 3), ("f64", 65536, 2), ("f64", 1 << 20, 1)])
 def test_c2c_long_powers_of_two(dtype, n, batch):
     rng = np.random.default_rng(n + batch)
     ct = np.complex128 if dtype == "f64" else np.complex64
@@ -400,7 +400,7 @@ def test_c2c_long_transforms_in_two_passes(n, batch, dtype, monkeypatch):
     assert torch.equal(torch.view_as_real(buf), torch.view_as_real(plan.c2c(zd)))
 
 
-@pytest.mark.parametrize("dtype,n", [("f64", 5000), ("f64", 12000), ("f32", 17000), ("f32", 20000)])
+@pytest.mark.parametrize("dtype,n", [("f64", 9000), ("f64", 12000), ("f32", 17000), ("f32", 20000)])
 def test_c2c_any_length_over_a_split_convolution(dtype, n):
     """Lengths whose chirp-z convolution (M >= 2n-1 points) is itself beyond a single kernel."""
     rng = np.random.default_rng(n)
@@ -455,14 +455,14 @@ def test_fftpy_spectrum_vectors_from_numpy_rfft(golden_dir):
 
 
 @pytest.mark.parametrize("n", [16384, 32768])
-def test_c2c_rows_kernels_many_frames_in_place(n):
-    """The long single-kernel transforms stride a resident grid over the batch (and the 16384-point
-    one requests the next frame early): more frames than CUs, an odd count, in place, both signs."""
+def test_c2c_longest_single_kernel_frames_in_place(n):
+    """The longest frames one workgroup holds in its registers: more frames than CUs, an odd count,
+    in place, both signs."""
     batch = 300 + 17
     g = torch.Generator(device="cuda").manual_seed(n)
     z = torch.view_as_complex(torch.rand((batch, n, 2), device="cuda", generator=g) * 2 - 1)
     plan = dsp_amd.FftPlan(n, "f32")
-    assert "rows" in plan.variant
+    assert "reg32x32" in plan.variant
     out = plan.c2c(z)
     for f in (0, 1, 255, 256, 257, batch - 1):
         want = oracle.dft(z[f].cpu().numpy().astype(np.complex128), -1, "radix2")
