@@ -5,6 +5,14 @@
 // synchronous, caller-owned-buffer behaviour of the reference's static
 // routines.  Any device failure prints the failing call and abort()s: these
 // routines return void in the reference, and there is no CPU fallback.
+//
+// The reference's callers run these routines once per period with the same
+// taps and window length (alsa/main.c:494-516 inside the capture loop,
+// fft/src/main.c:343-349), so plans and staging buffers are kept between
+// calls: the last few transform lengths and tap sets per device, and staging
+// buffers that only grow (anything over 256 MiB is given back at the end of the
+// call).  One mutex serialises the wrappers; dspmi_dropin_release() frees
+// everything that is kept.
 #include "common.h"
 
 #include <cmath>
@@ -25,15 +33,142 @@ int phase_f64(double *phi, const double *bins, unsigned nbin, unsigned in_stride
 
 namespace {
 
-// RAII device buffer for the wrapper path.
-struct DevBuf {
-    void *p = nullptr;
-    explicit DevBuf(size_t bytes) { DSPMI_HIP_OR_DIE(hipMalloc(&p, bytes ? bytes : 8)); }
-    ~DevBuf() { (void)hipFree(p); }
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    template <typename T> T *as() { return static_cast<T *>(p); }
+// What the wrappers keep between calls.  Never destroyed at exit (the HIP runtime may be gone by
+// then); dspmi_dropin_release() empties it.
+struct Kept {
+    std::mutex m;
+    unsigned long clock = 0;
+    struct Fft {
+        int dev;
+        unsigned n;
+        dspmi_fft_t plan;
+        unsigned long used;
+    };
+    struct Fir {
+        int dev;
+        std::vector<double> taps;
+        dspmi_fir_t plan;
+        unsigned long used;
+    };
+    struct Buf {
+        int dev, slot;
+        void *p;
+        size_t bytes;
+    };
+    std::vector<Fft> fft;
+    std::vector<Fir> fir;
+    std::vector<Buf> bufs;
 };
+constexpr size_t kKeepFft = 6, kKeepFir = 4;
+constexpr size_t kKeepBufBytes = (size_t)256 << 20;
+constexpr unsigned kKeepFftPoints = 1u << 20;  // longer plans own hundreds of MiB of work frames: made and destroyed per call
+
+Kept &kept()
+{
+    static Kept *k = new Kept;
+    return *k;
+}
+
+int current_device()
+{
+    int dev = 0;
+    DSPMI_HIP_OR_DIE(hipGetDevice(&dev));
+    return dev;
+}
+
+// staging buffer `slot` of the current device, at least `bytes` long (contents undefined)
+void *staging(int slot, size_t bytes)
+{
+    Kept &k = kept();
+    const int dev = current_device();
+    if (bytes == 0) bytes = 8;
+    for (Kept::Buf &b : k.bufs)
+        if (b.dev == dev && b.slot == slot) {
+            if (b.bytes < bytes) {
+                DSPMI_HIP_OR_DIE(hipFree(b.p));
+                b.p = nullptr;
+                b.bytes = 0;
+                DSPMI_HIP_OR_DIE(hipMalloc(&b.p, bytes));
+                b.bytes = bytes;
+            }
+            return b.p;
+        }
+    Kept::Buf b{dev, slot, nullptr, bytes};
+    DSPMI_HIP_OR_DIE(hipMalloc(&b.p, bytes));
+    k.bufs.push_back(b);
+    return b.p;
+}
+
+// end of a call: large staging buffers go back to the device
+void trim_staging()
+{
+    Kept &k = kept();
+    for (size_t i = 0; i < k.bufs.size();)
+        if (k.bufs[i].bytes > kKeepBufBytes) {
+            DSPMI_HIP_OR_DIE(hipFree(k.bufs[i].p));
+            k.bufs.erase(k.bufs.begin() + (long)i);
+        } else {
+            i++;
+        }
+}
+
+// A transform plan of n points in double precision on the current device; `owned` tells the
+// caller to destroy it after use (too long to keep).
+dspmi_fft_t fft_plan(unsigned n, bool *owned)
+{
+    Kept &k = kept();
+    const int dev = current_device();
+    *owned = false;
+    for (Kept::Fft &e : k.fft)
+        if (e.dev == dev && e.n == n) {
+            e.used = ++k.clock;
+            return e.plan;
+        }
+    dspmi_fft_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fft_create(&plan, n, DSPMI_F64, dev));
+    if (n > kKeepFftPoints) {
+        *owned = true;
+        return plan;
+    }
+    if (k.fft.size() >= kKeepFft) {
+        size_t old = 0;
+        for (size_t i = 1; i < k.fft.size(); i++)
+            if (k.fft[i].used < k.fft[old].used) old = i;
+        DSPMI_OR_DIE(dspmi_fft_destroy(k.fft[old].plan));
+        k.fft.erase(k.fft.begin() + (long)old);
+    }
+    k.fft.push_back({dev, n, plan, ++k.clock});
+    return plan;
+}
+
+void fft_done(dspmi_fft_t plan, bool owned)
+{
+    if (owned) DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+    trim_staging();
+}
+
+// A double-precision FIR plan for these taps on the current device (compared value by value).
+dspmi_fir_t fir_plan(const double *h, unsigned nh)
+{
+    Kept &k = kept();
+    const int dev = current_device();
+    for (Kept::Fir &e : k.fir)
+        if (e.dev == dev && e.taps.size() == nh && std::memcmp(e.taps.data(), h, (size_t)nh * sizeof(double)) == 0) {
+            e.used = ++k.clock;
+            return e.plan;
+        }
+    dspmi_fir_t plan = nullptr;
+    DSPMI_OR_DIE(dspmi_fir_create_f64(&plan, h, nh, dev));
+    if (k.fir.size() >= kKeepFir) {
+        size_t old = 0;
+        for (size_t i = 1; i < k.fir.size(); i++)
+            if (k.fir[i].used < k.fir[old].used) old = i;
+        DSPMI_OR_DIE(dspmi_fir_destroy(k.fir[old].plan));
+        k.fir.erase(k.fir.begin() + (long)old);
+    }
+    k.fir.push_back({dev, std::vector<double>(h, h + nh), plan, ++k.clock});
+    return plan;
+}
 
 enum Order { ASCENDING, DESCENDING };
 
@@ -45,17 +180,15 @@ void run_fir(double *y, unsigned nxx, const double *x, unsigned nx, const double
         std::memset(y, 0, (size_t)nxx * sizeof(double));
         return;
     }
-    dspmi_fir_t plan = nullptr;
-    DSPMI_OR_DIE(dspmi_fir_create_f64(&plan, h, nh, -1));
-    DevBuf dx((size_t)nx * sizeof(double)), dy((size_t)nxx * sizeof(double));
-    if (nx) DSPMI_HIP_OR_DIE(hipMemcpy(dx.p, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
-    if (order == DESCENDING)
-        DSPMI_OR_DIE(dspmi_fir_exec_f64_desc(plan, dy.as<double>(), nxx, nxx, dx.as<double>(), nx, nx, 1, flags, nullptr));
-    else
-        DSPMI_OR_DIE(dspmi_fir_exec_f64(plan, dy.as<double>(), nxx, nxx, dx.as<double>(), nx, nx, 1, nullptr, 0, flags,
-                                        nullptr));
-    DSPMI_HIP_OR_DIE(hipMemcpy(y, dy.p, (size_t)nxx * sizeof(double), hipMemcpyDeviceToHost));
-    DSPMI_OR_DIE(dspmi_fir_destroy(plan));
+    std::lock_guard<std::mutex> lock(kept().m);
+    dspmi_fir_t plan = fir_plan(h, nh);
+    double *dx = static_cast<double *>(staging(0, (size_t)nx * sizeof(double)));
+    double *dy = static_cast<double *>(staging(1, (size_t)nxx * sizeof(double)));
+    if (nx) DSPMI_HIP_OR_DIE(hipMemcpy(dx, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice));
+    if (order == DESCENDING) DSPMI_OR_DIE(dspmi_fir_exec_f64_desc(plan, dy, nxx, nxx, dx, nx, nx, 1, flags, nullptr));
+    else DSPMI_OR_DIE(dspmi_fir_exec_f64(plan, dy, nxx, nxx, dx, nx, nx, 1, nullptr, 0, flags, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(y, dy, (size_t)nxx * sizeof(double), hipMemcpyDeviceToHost));
+    trim_staging();
 }
 
 std::mutex g_fir_mutex;
@@ -68,14 +201,15 @@ std::vector<double> g_fir_taps = {  // alsa/main.c:389-407
 void run_c2c(double (*in)[2], unsigned nx, double (*out)[2], int sign)
 {
     if (nx == 0) return;
-    dspmi_fft_t plan = nullptr;
-    DSPMI_OR_DIE(dspmi_fft_create(&plan, nx, DSPMI_F64, -1));
+    std::lock_guard<std::mutex> lock(kept().m);
+    bool owned = false;
+    dspmi_fft_t plan = fft_plan(nx, &owned);
     const size_t bytes = (size_t)nx * 2 * sizeof(double);
-    DevBuf din(bytes), dout(bytes);
-    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, in, bytes, hipMemcpyHostToDevice));
-    DSPMI_OR_DIE(dspmi_fft_exec_c2c(plan, din.p, dout.p, 1, sign, nullptr));
-    DSPMI_HIP_OR_DIE(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
-    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+    void *din = staging(0, bytes), *dout = staging(1, bytes);
+    DSPMI_HIP_OR_DIE(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_c2c(plan, din, dout, 1, sign, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    fft_done(plan, owned);
 }
 
 }  // namespace
@@ -134,28 +268,31 @@ void dsp_idft(double (*in)[2], unsigned int nx, double (*out)[2]) { run_c2c(in, 
 void dsp_fft_r2c(double *xx, const double *x, unsigned int n)
 {
     if (n == 0) return;
-    dspmi_fft_t plan = nullptr;
-    DSPMI_OR_DIE(dspmi_fft_create(&plan, n, DSPMI_F64, -1));
+    std::lock_guard<std::mutex> lock(kept().m);
+    bool owned = false;
+    dspmi_fft_t plan = fft_plan(n, &owned);
     const unsigned nbin = n / 2 + 1;
-    DevBuf din((size_t)n * sizeof(double)), dout((size_t)nbin * 2 * sizeof(double));
-    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    DSPMI_OR_DIE(dspmi_fft_exec_r2c(plan, din.p, dout.p, 1, nullptr));
-    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dout.p, (size_t)nbin * 2 * sizeof(double), hipMemcpyDeviceToHost));
-    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+    void *din = staging(0, (size_t)n * sizeof(double)), *dout = staging(1, (size_t)nbin * 2 * sizeof(double));
+    DSPMI_HIP_OR_DIE(hipMemcpy(din, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_r2c(plan, din, dout, 1, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dout, (size_t)nbin * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    fft_done(plan, owned);
 }
 
 void dsp_fft_mag(double (*x)[2], unsigned int nx, double *xx)
 {
     if (nx < 2) return;
-    dspmi_fft_t plan = nullptr;
-    DSPMI_OR_DIE(dspmi_fft_create(&plan, nx, DSPMI_F64, -1));
+    std::lock_guard<std::mutex> lock(kept().m);
+    bool owned = false;
+    dspmi_fft_t plan = fft_plan(nx, &owned);
     const size_t bytes = (size_t)nx * 2 * sizeof(double);
-    DevBuf din(bytes), dout(bytes), dmag((size_t)(nx / 2) * sizeof(double));
-    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, x, bytes, hipMemcpyHostToDevice));
-    DSPMI_OR_DIE(dspmi_fft_exec_c2c(plan, din.p, dout.p, 1, DSPMI_FORWARD, nullptr));
-    DSPMI_OR_DIE(dspmi::ps_abs_f64(dout.p, dmag.as<double>(), nx / 2, (double)nx, 1, nx, nullptr));
-    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dmag.p, (size_t)(nx / 2) * sizeof(double), hipMemcpyDeviceToHost));
-    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+    void *din = staging(0, bytes), *dout = staging(1, bytes);
+    double *dmag = static_cast<double *>(staging(2, (size_t)(nx / 2) * sizeof(double)));
+    DSPMI_HIP_OR_DIE(hipMemcpy(din, x, bytes, hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_c2c(plan, din, dout, 1, DSPMI_FORWARD, nullptr));
+    DSPMI_OR_DIE(dspmi::ps_abs_f64(dout, dmag, nx / 2, (double)nx, 1, nx, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dmag, (size_t)(nx / 2) * sizeof(double), hipMemcpyDeviceToHost));
+    fft_done(plan, owned);
 }
 
 // nx/2 values read out of a transform of nx points: `mode` of the spectrum kernel, or the phase
@@ -163,11 +300,14 @@ static void run_readout(double (*x)[2], unsigned nx, double *out, int mode)
 {
     const unsigned nbin = nx / 2;
     if (nbin == 0) return;
-    DevBuf din((size_t)nbin * 2 * sizeof(double)), dout((size_t)nbin * sizeof(double));
-    DSPMI_HIP_OR_DIE(hipMemcpy(din.p, x, (size_t)nbin * 2 * sizeof(double), hipMemcpyHostToDevice));
-    if (mode < 0) DSPMI_OR_DIE(dspmi::phase_f64(dout.as<double>(), din.as<double>(), nbin, nbin, 1, nullptr));
-    else DSPMI_OR_DIE(dspmi::power_spectrum_f64(dout.as<double>(), din.as<double>(), nbin, nbin, 1, mode, (double)nx, nullptr));
-    DSPMI_HIP_OR_DIE(hipMemcpy(out, dout.p, (size_t)nbin * sizeof(double), hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lock(kept().m);
+    double *din = static_cast<double *>(staging(0, (size_t)nbin * 2 * sizeof(double)));
+    double *dout = static_cast<double *>(staging(1, (size_t)nbin * sizeof(double)));
+    DSPMI_HIP_OR_DIE(hipMemcpy(din, x, (size_t)nbin * 2 * sizeof(double), hipMemcpyHostToDevice));
+    if (mode < 0) DSPMI_OR_DIE(dspmi::phase_f64(dout, din, nbin, nbin, 1, nullptr));
+    else DSPMI_OR_DIE(dspmi::power_spectrum_f64(dout, din, nbin, nbin, 1, mode, (double)nx, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(out, dout, (size_t)nbin * sizeof(double), hipMemcpyDeviceToHost));
+    trim_staging();
 }
 
 void dsp_ps_percent(double (*x)[2], unsigned int nx, double *xx) { run_readout(x, nx, xx, DSPMI_PS_PERCENT); }
@@ -208,15 +348,34 @@ void dsp_make_filter_kernel(const double *fresp, unsigned int nx, double (*kerne
 void dsp_filter(double *xx, const double *x, unsigned int n, const double *coeffs)
 {
     if (n == 0) return;
-    dspmi_fft_t plan = nullptr;
-    DSPMI_OR_DIE(dspmi_fft_create(&plan, n, DSPMI_F64, -1));
+    std::lock_guard<std::mutex> lock(kept().m);
+    bool owned = false;
+    dspmi_fft_t plan = fft_plan(n, &owned);
     const unsigned nbin = n / 2 + 1;
-    DevBuf dx((size_t)n * sizeof(double)), dg((size_t)nbin * sizeof(double));
-    DSPMI_HIP_OR_DIE(hipMemcpy(dx.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    DSPMI_HIP_OR_DIE(hipMemcpy(dg.p, coeffs, (size_t)nbin * sizeof(double), hipMemcpyHostToDevice));
-    DSPMI_OR_DIE(dspmi_fft_exec_filter(plan, dx.p, dx.p, dg.p, 1, nullptr));
-    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dx.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    DSPMI_OR_DIE(dspmi_fft_destroy(plan));
+    void *dx = staging(0, (size_t)n * sizeof(double)), *dg = staging(1, (size_t)nbin * sizeof(double));
+    DSPMI_HIP_OR_DIE(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    DSPMI_HIP_OR_DIE(hipMemcpy(dg, coeffs, (size_t)nbin * sizeof(double), hipMemcpyHostToDevice));
+    DSPMI_OR_DIE(dspmi_fft_exec_filter(plan, dx, dx, dg, 1, nullptr));
+    DSPMI_HIP_OR_DIE(hipMemcpy(xx, dx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    fft_done(plan, owned);
+}
+
+void dspmi_dropin_release(void)
+{
+    Kept &k = kept();
+    std::lock_guard<std::mutex> lock(k.m);
+    int prev = 0;
+    DSPMI_HIP_OR_DIE(hipGetDevice(&prev));
+    for (Kept::Fft &e : k.fft) DSPMI_OR_DIE(dspmi_fft_destroy(e.plan));
+    for (Kept::Fir &e : k.fir) DSPMI_OR_DIE(dspmi_fir_destroy(e.plan));
+    for (Kept::Buf &b : k.bufs) {
+        DSPMI_HIP_OR_DIE(hipSetDevice(b.dev));
+        DSPMI_HIP_OR_DIE(hipFree(b.p));
+    }
+    DSPMI_HIP_OR_DIE(hipSetDevice(prev));
+    k.fft.clear();
+    k.fir.clear();
+    k.bufs.clear();
 }
 
 }  // extern "C"

@@ -70,6 +70,7 @@ _SIGS = {
     "dspmi_tonegen_f32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
     "dspmi_tonegen_c32": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
     "dspmi_tonegen_s16x2": (C.c_int, [_vp, _sz, _u, _u, _u, _vp, _vp, _vp, _vp, C.c_int, _u, _vp]),
+    "dspmi_dropin_release": (None, []),
     "dsp_conv0": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_conv1": (None, [_dp, _u, _dp, _u, _dp]),
     "dsp_convolve": (None, [_dp, _u, _dp, _u, _dp, _u]),

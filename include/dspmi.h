@@ -367,6 +367,14 @@ int dspmi_tonegen_s16x2(int16_t *x, size_t x_stride, unsigned n, unsigned nchan,
 /* Host drop-in wrappers (reference signatures; host double buffers)         */
 /* ------------------------------------------------------------------------ */
 
+/* The reference's callers run these routines once per period with the same taps and window
+ * length (alsa/main.c:494-516 in the capture loop, fft/src/main.c:343-349), so the wrappers keep
+ * what a call set up: the last 4 tap sets and 6 transform lengths (up to 2^20 points) per device
+ * as plans, and staging buffers that only grow (over 256 MiB: given back when the call ends).
+ * One mutex serialises them.  dspmi_dropin_release has no counterpart in the reference: it
+ * frees everything the wrappers keep (call it with no wrapper running, e.g. before exit). */
+void dspmi_dropin_release(void);
+
 /* convolution/main.c:15-33 */
 void dsp_conv0(const double *x, unsigned int nx, const double *h, unsigned int nh,
                double *y);

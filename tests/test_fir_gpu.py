@@ -80,6 +80,39 @@ def test_wrapper_long_kernel_multi_segment():
         assert np.array_equal(dsp_amd.conv0(x, h), oracle.conv0(x, h))
 
 
+def test_wrappers_keep_plans_between_calls_and_release_them():
+    """The wrappers keep the plans and staging buffers of the last few tap sets and transform
+    lengths (the reference calls them once per period with the same taps: alsa/main.c:494-516).
+    More tap sets and lengths than are kept, in an order that evicts and revisits; growing and
+    shrinking signals through the same staging buffers; every result bit for bit (FIR) or to the
+    double tolerance (transforms) as on a first call; dspmi_dropin_release gives the memory back."""
+    rng = np.random.default_rng(77)
+    taps = [rng.standard_normal(nh) for nh in (16, 21, 5, 127, 16, 964)]   # two different 16-tap sets
+    free0 = None
+    for rnd in range(3):
+        if rnd == 1:   # round 0 also loaded the kernels and set up the library's own state: measure from here
+            torch.cuda.synchronize()
+            free0, _ = torch.cuda.mem_get_info()
+        for i in (0, 1, 2, 3, 4, 5, 0, 4, 1):
+            nx = int(rng.integers(1, 5000))
+            x = rng.standard_normal(nx)
+            assert np.array_equal(dsp_amd.conv0(x, taps[i]), oracle.conv0(x, taps[i])), (rnd, i, nx)
+            assert np.array_equal(dsp_amd.convolve(x, taps[i], nx + len(taps[i])),
+                                  oracle.convolve(x, taps[i], nx + len(taps[i]))), (rnd, i, nx)
+        for n in (64, 480, 1024, 482, 4096, 100, 8, 2048, 64, 480, 1024):
+            z = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            want = oracle.dft(z, -1, "direct")
+            assert np.linalg.norm(dsp_amd.dft(z) - want) <= 1e-13 * np.linalg.norm(want), (rnd, n)
+            xr = rng.standard_normal(n)
+            wr = oracle.fft_r2c(xr)
+            assert np.linalg.norm(dsp_amd.fft_r2c(xr) - wr) <= 1e-13 * np.linalg.norm(wr), (rnd, n)
+        dsp_amd.lib().dspmi_dropin_release()
+        if free0 is not None:
+            torch.cuda.synchronize()
+            free1, _ = torch.cuda.mem_get_info()
+            assert free1 >= free0 - (4 << 20), (rnd, free0, free1)   # nothing of the wrappers' is left on the device
+
+
 # ---- f32 device API -----------------------------------------------------------------
 
 @pytest.fixture(params=["auto", "mfma", "ols"])
