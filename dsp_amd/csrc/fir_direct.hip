@@ -500,6 +500,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int kSplitMaxSlices = 10;
+constexpr int kHalfMaxSlices = 17;  // the f16 kernel alone: its tap images are 8 registers a slice
 constexpr size_t split_lds_bytes(int ns) { return (size_t)2 * 3 * (kSplitTile + 32 * ns - 16) * 2; }  // two sets of three planes
 
 // bf16(lo) in the low half, bf16(hi) in the high half, both rounded to nearest even
@@ -786,7 +787,7 @@ struct StoreSink {
 // (Four workgroups per CU up to five slices: at five the walker needs three registers fewer than
 // the compiler takes unasked, and finds them without spilling.)
 template <int NS, int TILE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS <= 5 ? 4 : 3))) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS <= 5 ? 4 : NS <= 10 ? 3 : 2))) void fir_half_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     StoreSink<TILE> sink(p);
@@ -822,6 +823,7 @@ struct dspmi_fir_plan {
     // ... and of the f16 kernel, with the factor that undoes the scale the taps were split under
     void *half_tab = nullptr;
     bool half_exec = false;  // dspmi_fir_exec_f32 runs the f16 kernel (shorter plans hold its tables for the fused filter + spectrum entry only)
+    unsigned half_rows_below = 0;  // overlap-save plans of 306 .. 529 taps: rows shorter than this run the f16 kernel
     float half_unscale = 1.f;
     char name[48] = "";
 };
@@ -1239,6 +1241,13 @@ int launch_half_tile(FirParams<float> p, const void *tab, float unscale, int ns,
     case 8: return launch_half_t<8, TILE>(p, tab, unscale, blocks, stream);
     case 9: return launch_half_t<9, TILE>(p, tab, unscale, blocks, stream);
     case 10: return launch_half_t<10, TILE>(p, tab, unscale, blocks, stream);
+    case 11: return launch_half_t<11, TILE>(p, tab, unscale, blocks, stream);
+    case 12: return launch_half_t<12, TILE>(p, tab, unscale, blocks, stream);
+    case 13: return launch_half_t<13, TILE>(p, tab, unscale, blocks, stream);
+    case 14: return launch_half_t<14, TILE>(p, tab, unscale, blocks, stream);
+    case 15: return launch_half_t<15, TILE>(p, tab, unscale, blocks, stream);
+    case 16: return launch_half_t<16, TILE>(p, tab, unscale, blocks, stream);
+    case 17: return launch_half_t<17, TILE>(p, tab, unscale, blocks, stream);
     }
     return dspmi::fail(DSPMI_EINVAL, "fir: no f16 kernel of %d slices", ns);
 }
@@ -1383,12 +1392,19 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         pl->variant = valu ? (nh <= 32 ? V_F32_SHORT : V_F32_LONG) : V_F32_MFMA;
         pl->pinned = valu || mfma;
         if constexpr (sizeof(T) == 4) {
-            const unsigned split_max = 32 * kSplitMaxSlices - 15;
+            const unsigned split_max = 32 * ((env && !strcmp(env, "f16")) ? kHalfMaxSlices : kSplitMaxSlices) - 15;
             // (plans below the f16 kernel's own range hold its tap images too, for the fused filter +
             // spectrum entry point; their FIR calls keep the f32 kernels)
             const bool tables_only = !env && nh < kSplitAutoMinTaps;
-            if (!valu && !mfma && !want_ols && (nh >= (want_split ? 1u : kSplitAutoMinTaps) || tables_only) && nh <= split_max) {
-                pl->half_exec = !tables_only;
+            // 306 .. 529 taps (11 .. 17 slices; 8 registers of tap images a slice, 226 in all at 17):
+            // the f16 kernel is bound by the matrix pipe there -- 440 Gsamples/s at 306 taps, 395 at
+            // 400, 343 at 511, whatever the row length from 4096 samples on -- where overlap-save runs
+            // 210-330 on rows of up to 65536 samples and 420-470 on rows of 2^20.  Such plans hold
+            // both, and a call takes the f16 kernel for rows below the measured crossover.
+            const bool mid_rows = !env && !(opts & DSPMI_FIR_FULL_RANGE) && nh > 32 * kSplitMaxSlices - 15 && nh <= 32 * kHalfMaxSlices - 15;
+            if (!valu && !mfma && !want_ols && (nh >= (want_split ? 1u : kSplitAutoMinTaps) || tables_only) && (nh <= split_max || mid_rows)) {
+                pl->half_exec = !tables_only && !mid_rows;
+                if (mid_rows) pl->half_rows_below = nh <= 32 * 13 - 15 ? (1u << 19) : (1u << 17);
                 pl->split_ns = (int)((nh + 15 + 31) / 32);
                 const std::vector<unsigned short> img = want_half ? half_tap_images(taps, nh, pl->split_ns, &pl->half_unscale)
                                                                   : split_tap_images(taps, nh, pl->split_ns);
@@ -1469,6 +1485,8 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     if constexpr (sizeof(T) == 4) {
         // overlap-save covers the plain case: as many outputs as inputs, rows long enough to
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
+        if (pl->half_rows_below && flags == 0 && nx < pl->half_rows_below)
+            return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
         if (pl->ols && flags == 0 && nxx == nx) {
             const unsigned long long work = (unsigned long long)nx * pl->nh;
             if (nx >= 2 * pl->ols_n && !(pl->ols_small && nx < 8 * pl->ols_n))
@@ -1533,7 +1551,7 @@ int fir_half_images(dspmi_fir_t plan, const void **images, float *unscale, int *
                     const float **taps)
 {
     if (!plan) return fail(DSPMI_EINVAL, "null FIR plan");
-    if (!plan->half_tab)
+    if (!plan->half_tab || plan->split_ns > kSplitMaxSlices)
         return fail(DSPMI_ENOSYS, "the FIR plan runs %s and holds no tap images of the f16 matrix kernel (plans of up to 305 taps do, unless DSPMI_FIR_VARIANT pins another kernel)", plan->name);
     *images = plan->half_tab;
     *unscale = plan->half_unscale;

@@ -711,6 +711,34 @@ def test_fir_and_spectrum_kernel_with_a_non_finite_sample():
         assert np.isfinite(got[c, f]).all() and rel_l2(got[c, f], want[c, f]) <= 1e-5, (c, f)
 
 
+@pytest.mark.parametrize("nh", [306, 417, 529])
+@pytest.mark.parametrize("nx", [700, 4096, 9000])
+def test_mid_length_filters_on_short_rows_run_the_f16_kernel(nh, nx):
+    """306 .. 529 taps (11 .. 17 slices): the plan is an overlap-save plan that also holds the f16
+    kernel's tap images and runs it on rows below the measured crossover -- with carried history,
+    with the nx + nh tail, and against the same plan created with DSPMI_FIR_FULL_RANGE, which keeps
+    overlap-save and the f32 kernels (fir/src/main.c:258-280 is the sum both restate)."""
+    rng = np.random.default_rng(nh + nx)
+    nchan = 19
+    x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
+    h = oracle.windowed_sinc_taps(nh).astype(np.float32)
+    hist = rng.uniform(-1, 1, (nchan, nh - 1)).astype(np.float32)
+    xd, hd = torch.from_numpy(x).cuda(), torch.from_numpy(hist).cuda()
+    want_h = oracle.fir_batch_f32(np.concatenate([hist, x], axis=1), h, nh - 1 + nx)[:, nh - 1:]
+    want_0 = oracle.fir_batch_f32(x, h, nx + nh)
+    plans = [dsp_amd.FirPlan(h, "f32"), dsp_amd.FirPlan(h, "f32", options=dsp_amd.FirPlan.FULL_RANGE)]
+    assert all("overlap_save" in pl.variant for pl in plans)
+    outs = []
+    for pl in plans:
+        got_h = pl.exec(xd, nx, hist=hd).cpu().numpy()
+        got_0 = pl.exec(xd, nx + nh).cpu().numpy()
+        outs.append(got_h)
+        for c in (0, nchan // 2, nchan - 1):
+            assert_blocks(got_h[c], want_h[c], h, x[c], (pl.variant, nh, nx, c, "history"))
+            assert_blocks(got_0[c], want_0[c], h, x[c], (pl.variant, nh, nx, c, "tail"))
+    assert not np.array_equal(outs[0], outs[1])   # two different kernels did the work
+
+
 @pytest.mark.parametrize("nh", [33, 127, 305])
 @pytest.mark.parametrize("nx", [100, 256, 1000, 1024, 1025, 1536, 2048, 2100, 3072, 5120, 6000])
 def test_f16_kernel_tiles_by_row_length(nh, nx, monkeypatch):
