@@ -39,14 +39,18 @@ struct FftKernel {
 // Kernel for a power-of-two length, or nullptr.
 const FftKernel *fft_find(unsigned n, int precision);
 
-// One pass of a long transform n = n1 n2 done in two (N = 256, 512 or 1024 points per column or
-// row): nframe frames of N x ncol points.  mode 1: `in` seen as [N][ncol], the N-point transforms
-// of its columns, times W_n^(column . k), left in `out` as tiles [k / 16][column / 16][k % 16][column % 16];
-// mode 2: `in` in those tiles (ncol values of k, N columns), the N-point transforms over the
-// columns, stored as columns of `out` seen as [N][ncol].  tw = exp(-2 pi i k / N); twa, twb, shift:
-// the two-table form of W_n.
+// One pass of a long transform done in two (n = n1 n2) or three (n = t1 t2 t3), N = 128 .. 1024 points
+// per column or row, nframe frames.  tw = exp(-2 pi i k / N); twa, twb, shift: the two-table form of W_n.
+//   mode 1: `in` seen as [N][ncol], the N-point transforms of its columns, times W_n^(column . k), left
+//           in `out` as tiles [k / 16][column / 16][k % 16][column % 16];
+//   mode 2: `in` in those tiles (ncol values of k, N columns), the N-point transforms over the
+//           columns, stored as columns of `out` seen as [N][ncol];
+//   mode 3: as mode 1 with the factors W_n^((column - column % p0) . k), result in place ([k][column]);
+//   mode 4: as mode 1 with the factors W_n^(column . (p0 k + frame % p0)), result in place;
+//   mode 5: frames seen as [p1][p0][N]: the N-point transforms of rows (kc, kb), stored as columns
+//           p1 kb + kc of `out` seen as [N][ncol], ncol = p0 p1.
 typedef int (*fft_bundle_fn)(const void *in, void *out, const void *tw, size_t nframe, unsigned ncol, const void *twa,
-                             const void *twb, unsigned shift, int mode, int backward, int num_cu, hipStream_t s);
+                             const void *twb, unsigned shift, int mode, int backward, unsigned p0, unsigned p1, hipStream_t s);
 fft_bundle_fn fft_bundle_find(unsigned n, int precision);
 
 // Fused overlap-save (f32): blocks of N samples overlapping by nh-1, two real blocks per

@@ -366,6 +366,8 @@ struct dspmi_fft_plan {
     dspmi_fft_plan *half_plan = nullptr;
     // power-of-two n beyond the longest single kernel: n = n1 * n2, two batched passes
     unsigned n1 = 0, n2 = 0, tw_shift = 0;
+    unsigned t1 = 0, t2 = 0, t3 = 0;  // n = t1 t2 t3 beyond 2^20 points: three column passes
+    void *tw_t1 = nullptr, *tw_t2 = nullptr, *tw_t3 = nullptr;
     const dspmi::FftKernel *kern_n1 = nullptr, *kern_n2 = nullptr;
     void *tw_n1 = nullptr, *tw_n2 = nullptr, *tw_hi = nullptr, *tw_lo = nullptr;
     // Bluestein whose convolution length M is itself beyond a single kernel
@@ -411,14 +413,19 @@ int four_step(dspmi_fft_plan *pl, const C<T> *in, C<T> *out, size_t batch, int b
 {
     const size_t n = pl->n;
     size_t cap = fixed_work ? fixed_bytes : ((size_t)128 << 20);
-    // Both factors 256 .. 1024 points (n = 2^16 .. 2^20): two passes, the transposes folded into
-    // the transforms' loads and stores (fft_c2c_colreg_kernel), one work frame per frame; groups of
-    // 256 MiB (larger launches count for more than what stays in the last-level cache between
-    // the passes).  DSPMI_FFT_FIVE_PASS=1 keeps the five-pass route below for A/B.
+    // Both factors 128 .. 1024 points (n up to 2^20): two passes, the transposes folded into the
+    // transforms' loads and stores (fft_c2c_colreg_kernel); beyond, three factors of 128 or 256
+    // points and three such passes.  One work frame per frame, in groups of 256 MiB (larger
+    // launches count for more than what stays in the last-level cache between the passes).
+    // DSPMI_FFT_FIVE_PASS=1 keeps the five-pass route below for A/B.
     {
         const int prec = sizeof(T) == 8 ? DSPMI_F64 : DSPMI_F32;
         const dspmi::fft_bundle_fn pass1 = dspmi::fft_bundle_find(pl->n2, prec), pass2 = dspmi::fft_bundle_find(pl->n1, prec);
-        if (pass1 && pass2 && !getenv("DSPMI_FFT_FIVE_PASS")) {
+        const dspmi::fft_bundle_fn pa = pl->t3 ? dspmi::fft_bundle_find(pl->t3, prec) : nullptr,
+                                   pb = pl->t3 ? dspmi::fft_bundle_find(pl->t2, prec) : nullptr,
+                                   pc = pl->t3 ? dspmi::fft_bundle_find(pl->t1, prec) : nullptr;
+        const bool two = pass1 && pass2, three = !two && pa && pb && pc;
+        if ((two || three) && !getenv("DSPMI_FFT_FIVE_PASS")) {
             if (!fixed_work) cap = (size_t)256 << 20;
             const size_t fb = n * sizeof(C<T>);
             if (fixed_work && fb > cap)
@@ -435,9 +442,20 @@ int four_step(dspmi_fft_plan *pl, const C<T> *in, C<T> *out, size_t batch, int b
             }
             for (size_t done = 0; done < batch; done += group) {
                 const size_t g = batch - done < group ? batch - done : group;
-                int rc = pass1(in + done * n, w, pl->tw_n2, g, pl->n1, pl->tw_hi, pl->tw_lo, pl->tw_shift, 1, backward, pl->num_cu, s);
+                int rc;
+                if (two) {
+                    rc = pass1(in + done * n, w, pl->tw_n2, g, pl->n1, pl->tw_hi, pl->tw_lo, pl->tw_shift, 1, backward, 0, 0, s);
+                    if (rc != DSPMI_OK) return rc;
+                    rc = pass2(w, out + done * n, pl->tw_n1, g, pl->n2, pl->tw_hi, pl->tw_lo, pl->tw_shift, 2, backward, 0, 0, s);
+                    if (rc != DSPMI_OK) return rc;
+                    continue;
+                }
+                // x[a + t1 (b + t2 c)]: over c, over b (one [t2][t1] frame per kc), over a
+                rc = pa(in + done * n, w, pl->tw_t3, g, pl->t1 * pl->t2, pl->tw_hi, pl->tw_lo, pl->tw_shift, 3, backward, pl->t1, 0, s);
                 if (rc != DSPMI_OK) return rc;
-                rc = pass2(w, out + done * n, pl->tw_n1, g, pl->n2, pl->tw_hi, pl->tw_lo, pl->tw_shift, 2, backward, pl->num_cu, s);
+                rc = pb(w, w, pl->tw_t2, g * pl->t3, pl->t1, pl->tw_hi, pl->tw_lo, pl->tw_shift, 4, backward, pl->t3, 0, s);
+                if (rc != DSPMI_OK) return rc;
+                rc = pc(w, out + done * n, pl->tw_t1, g, pl->t2 * pl->t3, pl->tw_hi, pl->tw_lo, pl->tw_shift, 5, backward, pl->t2, pl->t3, s);
                 if (rc != DSPMI_OK) return rc;
             }
             return DSPMI_OK;
@@ -840,6 +858,17 @@ int create_plan(dspmi_fft_t *plan, unsigned n, int precision, int device, bool c
         pl->tw_shift = (lg + 1) / 2;
         rc = upload_twiddles(&pl->tw_n1, n1, precision);
         if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_n2, n2, precision);
+        if (lg > 20) {
+            // three factors of 128 .. 256 points, the longest first in memory order (t3)
+            const unsigned l1 = lg / 3, l2 = (lg - l1) / 2, l3 = lg - l1 - l2;
+            pl->t1 = 1u << l1;
+            pl->t2 = 1u << l2;
+            pl->t3 = 1u << l3;
+            if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_t1, pl->t1, precision);
+            if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_t2, pl->t2, precision);
+            if (rc == DSPMI_OK) rc = upload_twiddles(&pl->tw_t3, pl->t3, precision);
+            snprintf(pl->name, sizeof pl->name, "fft_%s_n%u_as_%ux%ux%u", precision == DSPMI_F64 ? "f64" : "f32", n, pl->t1, pl->t2, pl->t3);
+        }
         if (rc == DSPMI_OK)
             rc = precision == DSPMI_F64 ? upload<double>(&pl->tw_hi, unit_circle<double>(n >> pl->tw_shift, 1))
                                         : upload<float>(&pl->tw_hi, unit_circle<float>(n >> pl->tw_shift, 1));
@@ -871,7 +900,7 @@ int dspmi_fft_destroy(dspmi_fft_t plan)
     if (!plan) return DSPMI_OK;
     if (plan->half_plan) (void)dspmi_fft_destroy(plan->half_plan);
     if (plan->plan_M) (void)dspmi_fft_destroy(plan->plan_M);
-    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->tw_n1, plan->tw_n2, plan->tw_hi, plan->tw_lo,
+    void *bufs[] = {plan->tw_n, plan->tw_half, plan->tw_M, plan->chirp, plan->filt, plan->tw_n1, plan->tw_n2, plan->tw_t1, plan->tw_t2, plan->tw_t3, plan->tw_hi, plan->tw_lo,
                     plan->work[0], plan->work[1], plan->work[2], plan->work[3], plan->work[4]};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

@@ -2336,16 +2336,27 @@ int launch_c2c_reg3(const void *in, void *out, const void *tw, size_t batch, int
 // [k2 / 16][a / 16][k2 % 16][a % 16], so that a wave stores 512 contiguous bytes and pass 2 reads
 // its 16 rows as one contiguous run of 128 N bytes; pass 2 stores rows of 16 adjacent columns of
 // the output.
+//
+// Three passes for n = t1 t2 t3 beyond 2^20 points, x[a + t1 (b + t2 c)] -> X[t2 t3 k1 + t3 kb + kc]
+// (the same identity applied twice; every pass leaves its result where it found its input, so one
+// work frame per frame serves all three):
+//   MODE 3  N = t3, ncol = t1 t2, p0 = t1: columns (b, a) over c, times W_(t2 t3)^(b kc) = W_n^(t1 b kc)
+//   MODE 4  N = t2, ncol = t1, p0 = t3, one frame per kc: columns a over b, times W_n^(a (t3 kb + kc))
+//   MODE 5  N = t1, ncol = t2 t3, p0 = t2, p1 = t3: the rows (kc, kb) of 16 adjacent kc over a, stored as
+//           16 adjacent columns t3 kb + kc of the output seen as [t1][t2 t3]
 template <typename T, int RA, int RB, int MODE>
 __global__ __launch_bounds__(16 * RB) void fft_c2c_colreg_kernel(const C<T> *in, C<T> *out, const C<T> *__restrict__ tw, unsigned bpf,
                                                                  unsigned ncol, const C<T> *__restrict__ twa,
-                                                                 const C<T> *__restrict__ twb, unsigned shift, int backward)
+                                                                 const C<T> *__restrict__ twb, unsigned shift, int backward,
+                                                                 unsigned p0, unsigned p1)
 {
     // RA >= RB: lane (kq, column) of the second radix takes M = RA / RB transforms, k % RA = kq + RB m;
     // RA < RB: one transform in the lanes with kq < RA, the others only keep the barriers company
     constexpr int N = RA * RB, M = RA >= RB ? RA / RB : 1, P = RA >= RB ? RA : RB, SB = RA + 1,
                   SC = RB * SB + (34 - (RB * SB) % 32) % 32;
     static_assert((RA >= RB ? M * RB == RA : RB % RA == 0) && RB % 16 == 0, "whole transforms per lane, whole tiles of 16 rows");
+    constexpr bool kColumnsIn = MODE == 1 || MODE == 3 || MODE == 4;   // natural [N][ncol] input, 16 adjacent columns
+    constexpr bool kConjIn = MODE == 1 || MODE == 3, kConjOut = MODE == 2 || MODE == 5;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T *cimg = reinterpret_cast<T *>(smem_raw);
     const unsigned tid = threadIdx.x;
@@ -2356,22 +2367,31 @@ __global__ __launch_bounds__(16 * RB) void fft_c2c_colreg_kernel(const C<T> *in,
 
     C<T> v[P];
     unsigned lo, col;
-    if constexpr (MODE == 1) {
+    if constexpr (kColumnsIn) {
         col = tid & 15;
         lo = tid >> 4;
         const C<T> *src = in + base + (size_t)lo * ncol + cb * 16 + col;
 #pragma unroll
         for (int j = 0; j < RA; j++) {
-            C<T> q = nt_load(src + (size_t)(RB * j) * ncol);
-            q.im *= sgn;
+            C<T> q = MODE == 4 ? src[(size_t)(RB * j) * ncol] : nt_load(src + (size_t)(RB * j) * ncol);
+            if constexpr (kConjIn) q.im *= sgn;
             v[j] = q;
         }
-    } else {
+    } else if constexpr (MODE == 2) {
         col = (tid >> 4) & 15;
         lo = (tid & 15) + 16 * (tid >> 8);
         const C<T> *src = in + base + (size_t)cb * (16 * N) + tid;
 #pragma unroll
         for (int j = 0; j < RA; j++) v[j] = src[RB * 16 * j];
+    } else {
+        // F = (frame, kb); row `col` of the bundle is row (16 cb + col, kb) of the frame's [t3][t2][N] image
+        col = tid / RB;
+        lo = tid % RB;
+        const size_t frame = F / p0;
+        const unsigned kb = (unsigned)(F - frame * p0);
+        const C<T> *src = in + frame * ((size_t)N * ncol) + ((size_t)(cb * 16 + col) * p0 + kb) * N + lo;
+#pragma unroll
+        for (int j = 0; j < RA; j++) v[j] = src[RB * j];
     }
     dft_reg<RA, 1>(v);
     {
@@ -2413,38 +2433,49 @@ __global__ __launch_bounds__(16 * RB) void fft_c2c_colreg_kernel(const C<T> *in,
 #pragma unroll
     for (int m = 0; m < M; m++) dft_reg<RB, 1>(&v[m * RB]);
     // v[m RB + kb] = X[kq + RB m + RA kb] of column colr
-    if constexpr (MODE == 1) {
-        const unsigned a = cb * 16 + colr, mask = (1u << shift) - 1;
+    if constexpr (kColumnsIn) {
+        // times W_n^(a (kmul k + kadd)): one look-up per transform, step factors for the rest
+        const unsigned a = MODE == 3 ? (cb * 16 / p0) * p0 : cb * 16 + colr, mask = (1u << shift) - 1;
+        const unsigned kmul = MODE == 4 ? p0 : 1u, kadd = MODE == 4 ? (unsigned)(F % p0) : 0u;
         auto W = [&](unsigned e) { return cmul(twa[e >> shift], twb[e & mask]); };  // W_n^e, e < n
         C<T> l[4], h[RB / 4];
-        const unsigned gstep = a * RA;
+        const unsigned gstep = a * kmul * RA;
 #pragma unroll
         for (int i = 1; i < 4; i++) l[i] = W(gstep * i);
 #pragma unroll
         for (int i = 1; i < RB / 4; i++) h[i] = W(gstep * 4 * i);
-        C<T> *dst = out + base + (size_t)cb * 256 + colr;
+        // MODE 1: tiles [k / 16][column / 16][k % 16][column % 16]; MODE 3, 4: back in place
+        C<T> *dst = out + base + (MODE == 1 ? (size_t)cb * 256 : (size_t)cb * 16) + colr;
         const size_t tile_pitch = (size_t)ncol * 16;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const C<T> b0 = W(a * (kq + RB * m));
+            const C<T> b0 = W(a * (kmul * (kq + RB * m) + kadd));
             const C<T> lb[4] = {b0, cmul(b0, l[1]), cmul(b0, l[2]), cmul(b0, l[3])};
 #pragma unroll
             for (int kb = 0; kb < RB; kb++) {
                 C<T> f = lb[kb % 4];
                 if (kb / 4) f = cmul(f, h[kb / 4]);
                 const unsigned k = kq + RB * m + RA * kb;
-                dst[(size_t)(k >> 4) * tile_pitch + (k & 15) * 16] = cmul(v[m * RB + kb], f);
+                if constexpr (MODE == 1) dst[(size_t)(k >> 4) * tile_pitch + (k & 15) * 16] = cmul(v[m * RB + kb], f);
+                else dst[(size_t)k * ncol] = cmul(v[m * RB + kb], f);
             }
         }
     } else {
-        C<T> *dst = out + base + cb * 16 + colr;
+        C<T> *dst;
+        if constexpr (MODE == 2) {
+            dst = out + base + cb * 16 + colr;
+        } else {
+            const size_t frame = F / p0;
+            const unsigned kb = (unsigned)(F - frame * p0);
+            dst = out + frame * ((size_t)N * ncol) + (size_t)p1 * kb + cb * 16 + colr;
+        }
 #pragma unroll
         for (int m = 0; m < M; m++)
 #pragma unroll
             for (int kb = 0; kb < RB; kb++) {
                 const unsigned k = kq + RB * m + RA * kb;
                 C<T> q = v[m * RB + kb];
-                q.im *= sgn;
+                if constexpr (kConjOut) q.im *= sgn;
                 nt_store(q, dst + (size_t)k * ncol);
             }
     }
@@ -2452,26 +2483,31 @@ __global__ __launch_bounds__(16 * RB) void fft_c2c_colreg_kernel(const C<T> *in,
 
 template <typename T, int RA, int RB>
 int launch_c2c_colreg(const void *in, void *out, const void *tw, size_t nframe, unsigned ncol, const void *twa, const void *twb,
-                      unsigned shift, int mode, int backward, int num_cu, hipStream_t s)
+                      unsigned shift, int mode, int backward, unsigned p0, unsigned p1, hipStream_t s)
 {
     constexpr int SB = RA + 1, SC = RB * SB + (34 - (RB * SB) % 32) % 32;
     constexpr size_t lds = (size_t)16 * SC * sizeof(T);
-    auto k1 = fft_c2c_colreg_kernel<T, RA, RB, 1>;
-    auto k2 = fft_c2c_colreg_kernel<T, RA, RB, 2>;
+    typedef void (*kern_t)(const C<T> *, C<T> *, const C<T> *, unsigned, unsigned, const C<T> *, const C<T> *, unsigned, int, unsigned,
+                           unsigned);
+    static const kern_t kerns[5] = {fft_c2c_colreg_kernel<T, RA, RB, 1>, fft_c2c_colreg_kernel<T, RA, RB, 2>,
+                                    fft_c2c_colreg_kernel<T, RA, RB, 3>, fft_c2c_colreg_kernel<T, RA, RB, 4>,
+                                    fft_c2c_colreg_kernel<T, RA, RB, 5>};
     static dspmi::PerDeviceOnce attr;
     if (attr.pending()) {
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (kern_t k : kerns)
+            DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr.mark();
     }
-    if (ncol % 16) return dspmi::fail(DSPMI_EINVAL, "fft: %u columns do not divide into bundles of 16", ncol);
-    const size_t nbundle = nframe * (ncol / 16);
+    if (mode < 1 || mode > 5) return dspmi::fail(DSPMI_EINVAL, "fft: column pass mode %d", mode);
+    // bundles of 16 columns per frame; mode 5: 16 of the p1 rows (kc) for each of the p0 rows kb
+    const unsigned bundled = mode == 5 ? p1 : ncol;
+    if (bundled % 16) return dspmi::fail(DSPMI_EINVAL, "fft: %u columns do not divide into bundles of 16", bundled);
+    const size_t nbundle = nframe * (mode == 5 ? (size_t)p0 : 1) * (bundled / 16);
     if (nbundle == 0) return DSPMI_OK;
     if (nbundle > 0x7fffffffu) return dspmi::fail(DSPMI_EINVAL, "fft: %zu column bundles in one launch", nbundle);
-    (void)num_cu;
-    hipLaunchKernelGGL(mode == 1 ? k1 : k2, dim3((unsigned)nbundle), dim3(16 * RB), lds, s, static_cast<const C<T> *>(in),
-                       static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), ncol / 16, ncol, static_cast<const C<T> *>(twa),
-                       static_cast<const C<T> *>(twb), shift, backward);
+    hipLaunchKernelGGL(kerns[mode - 1], dim3((unsigned)nbundle), dim3(16 * RB), lds, s, static_cast<const C<T> *>(in),
+                       static_cast<C<T> *>(out), static_cast<const C<T> *>(tw), bundled / 16, ncol, static_cast<const C<T> *>(twa),
+                       static_cast<const C<T> *>(twb), shift, backward, p0, p1);
     DSPMI_HIP(hipGetLastError());
     return DSPMI_OK;
 }
@@ -2736,6 +2772,7 @@ fft_bundle_fn fft_bundle_find(unsigned n, int precision)
         default: return nullptr;
         }
     switch (n) {
+    case 128: return launch_c2c_colreg<float, 8, 16>;
     case 256: return launch_c2c_colreg<float, 16, 16>;
     case 512: return launch_c2c_colreg<float, 32, 16>;
     case 1024: return launch_c2c_colreg<float, 32, 32>;

@@ -373,11 +373,11 @@ def test_c2c_long_powers_of_two(dtype, n, batch):
 
 @pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("n,batch", [(1 << 14, 9), (1 << 15, 4), (1 << 16, 5), (1 << 17, 3), (1 << 18, 2), (1 << 19, 2), (1 << 20, 3),
-                                     (1 << 21, 1)])
-def test_c2c_long_transforms_in_two_passes(n, batch, dtype, monkeypatch):
-    """2^16 .. 2^20 points (from 2^14 in double precision, where one kernel holds 8192 points at
-    most): two passes over memory, the transposes folded into the transforms' loads and stores;
-    2^21 points and beyond, and DSPMI_FFT_FIVE_PASS=1, take the five-pass route.  Both
+                                     (1 << 21, 3), (1 << 22, 2), (1 << 23, 1), (1 << 24, 1)])
+def test_c2c_long_transforms_in_two_or_three_passes(n, batch, dtype, monkeypatch):
+    """Beyond the single-kernel lengths: two passes over memory up to 2^20 points, the transposes
+    folded into the transforms' loads and stores, and three such passes (n = t1 t2 t3, factors of
+    128 or 256 points) from 2^21 to 2^24; DSPMI_FFT_FIVE_PASS=1 takes the five-pass route.  Both
     against the oracle on one frame, forward and backward, and against each other on every frame."""
     ct, tol, same = (np.complex64, TOL_FFT, 1e-6) if dtype == "f32" else (np.complex128, TOL_F64, 1e-14)
     rng = np.random.default_rng(n)
