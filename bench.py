@@ -156,6 +156,25 @@ def make_fft(args, rank):
     return (lambda: plan.c2c(z, dsp_amd.FORWARD, out=out)), info, (plan, z, out, both)
 
 
+def make_fft_len(n, dtype):
+    """Secondary lines: other transform lengths and double precision (the precision of the
+    reference's own fftw calls, fftc/main.c:31-43), 1 GiB of frames in and 1 GiB out."""
+    esz = 8 if dtype == "f32" else 16
+    frames = (1 << 30) // (n * esz)
+    both = torch.empty((2, frames, n, 2), dtype=torch.float32 if dtype == "f32" else torch.float64, device="cuda")
+    both[0].uniform_(-1.0, 1.0, generator=torch.Generator(device="cuda").manual_seed(0xD5B0 + n))
+    z, out = torch.view_as_complex(both[0]), torch.view_as_complex(both[1])
+    plan = dsp_amd.FftPlan(n, dtype)
+    info = dict(kernel=plan.variant, units=frames, unit_name="frames", n=n, flop_per_unit=5.0 * n * math.log2(n),
+                bytes_per_unit=2.0 * n * esz, bound="hbm", samples_per_unit=n,
+                workload="batched c2c %s FFT, N=%d, %d frames, out of place" % (dtype, n, frames))
+    passes = plan.variant.split("_as_")[1].count("x") + 1 if "_as_" in plan.variant else 1
+    if passes > 1:
+        info["note"] = ("%d passes over memory (one work frame between them): `achieved` counts the algorithmic bytes of "
+                        "one read and one write, each pass moves them once" % passes)
+    return (lambda: plan.c2c(z, dsp_amd.FORWARD, out=out)), info, (plan, z, out, both)
+
+
 def sinc_taps(nh):
     k = np.arange(nh, dtype=np.float64) - (nh - 1) / 2.0
     h = np.sinc(2.0 * 6000.0 / 48000.0 * k) * (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(nh) / (nh - 1)))
@@ -622,7 +641,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         del keep, fn
         torch.cuda.empty_cache()
-        jobs = [("fir", 16, False), ("fir", 127, False), ("fir", 127, True), ("ols8191",), ("fir8191",), ("chain", 127), ("chain", 16)]
+        jobs = [("fir", 16, False), ("fir", 127, False), ("fir", 127, True), ("ols8191",), ("fir8191",), ("chain", 127), ("chain", 16),
+                ("fft", 16384, "f32"), ("fft", 32768, "f32"), ("fft", 1 << 20, "f32"), ("fft", 1 << 24, "f32"),
+                ("fft", 1024, "f64"), ("fft", 8192, "f64"), ("fft", 1 << 20, "f64")]
         for job in jobs:
             if job[0] == "fir":
                 _, nh, direct = job
@@ -630,6 +651,9 @@ def main():
                     continue
                 f2, i2, k2 = make_fir(args, rank, nh, direct)
                 nsec, nwarm = 20, 40
+            elif job[0] == "fft":
+                f2, i2, k2 = make_fft_len(job[1], job[2])
+                nsec, nwarm = 20, 10
             elif job[0] == "chain":
                 args.chain_taps = job[1]
                 f2, i2, k2 = make_chain(args, rank)
@@ -642,7 +666,7 @@ def main():
             # headline's 200 launches do for themselves.
             d2, ms2, med2 = timed(f2, nsec, nwarm, 1)
             ent = {"workload": i2["workload"],
-                   "gsamples_per_s": round(i2["units"] * nsec / d2 / 1e9, 2),
+                   "gsamples_per_s": round(i2.get("samples_per_unit", 1) * i2["units"] * nsec / d2 / 1e9, 2),
                    flops_key(i2): round(i2["flop_per_unit"] * i2["units"] * nsec / d2 / 1e9, 1),
                    "ms_per_step": round(d2 / nsec * 1e3, 4),
                    "roofline": roofline(i2, ms2, med2)}
