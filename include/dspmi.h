@@ -199,7 +199,8 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
  * the reference.  Same arguments and results as dspmi_fft_exec_c2c; the difference is where
  * the multi-kernel transforms keep their work frames (the any-length transform in double
  * precision: batch * M * 16 bytes, M = the power of two >= 2n-1; powers of two beyond the
- * longest single kernel: 2 * n points per frame, frames going through in groups that fit):
+ * longest single kernel: n points per frame -- f32 up to 2^21 points, f64 up to 2^20 --, frames
+ * going through in groups that fit):
  * not in the plan's own buffer, which an execute may have to grow, but in a static device
  * array of DSPMI_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the
  * process ends.  The call performs no hipMalloc / hipFree.  Work frames that exceed the array

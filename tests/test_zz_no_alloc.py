@@ -18,11 +18,12 @@ def _frames(batch, n, dtype, seed):
 
 
 @pytest.mark.parametrize("n,dtype", [(480, "f64"), (482, "f64"), (1000, "f64"), (480, "f32"), (1024, "f64"), (32768, "f64"),
-                                     (65536, "f32")])
+                                     (65536, "f32"), (1 << 20, "f64"), (1 << 21, "f32")])
 def test_no_alloc_c2c_matches_the_allocating_entry_point(n, dtype):
     ct = np.complex128 if dtype == "f64" else np.complex64
     plan = dsp_amd.FftPlan(n, dtype)
-    for call, (batch, sign) in enumerate([(37, dsp_amd.FORWARD), (5, dsp_amd.BACKWARD)]):
+    big = n >= 1 << 20   # two and three column passes, one work frame that fills the static array
+    for call, (batch, sign) in enumerate([(7 if big else 37, dsp_amd.FORWARD), (2 if big else 5, dsp_amd.BACKWARD)]):
         z = _frames(batch, n, ct, 100 * n + call)
         want = plan.c2c(z, sign)
         got = torch.full_like(z, float("nan"))
@@ -76,3 +77,10 @@ def test_no_alloc_c2c_on_a_fresh_plan_leaves_device_memory_alone(n, dtype, batch
     assert free_after == free_before, (free_before, free_after)
     want = dsp_amd.FftPlan(n, dtype).c2c(z, dsp_amd.FORWARD)
     assert torch.equal(torch.view_as_real(got), torch.view_as_real(want))
+
+
+def test_no_alloc_c2c_refuses_frames_longer_than_the_static_array():
+    plan = dsp_amd.FftPlan(1 << 22, "f32")      # 32 MiB per work frame
+    z = torch.zeros((1, 1 << 22), dtype=torch.complex64, device="cuda")
+    rc = dsp_amd.lib().dspmi_fft_exec_c2c_noalloc(plan._h, z.data_ptr(), z.data_ptr(), 1, -1, None)
+    assert rc == -22 and b"static" in dsp_amd.lib().dspmi_last_error()
