@@ -2201,29 +2201,16 @@ const BluesteinEntry kBluesteinF32[] = {
 // over k1 and padded planes in the second).  Half the LDS of a frame image of complex points, so
 // two workgroups fit a CU at 16384 points in single precision and one loads while the other
 // computes; 32768 points fit at all.
-template <typename T, int P, int RC, int NTMEM>
-__global__ __launch_bounds__(P * RC) void fft_c2c_reg3_kernel(const C<T> *in, C<T> *out, const C<T> *__restrict__ tw, size_t batch,
-                                                              int flags)
+// The forward transform of the points a workgroup's lanes hold: in, v[j] = x[t + L j]; out,
+// v[i RC + q0] = X[t + L (i + TC q0)] -- the same set of indices t + L j per lane, so a second
+// transform can follow in registers (after a permutation of register names).  SYNC_FIRST: the image
+// may still be read by other lanes (a transform went before).
+template <typename T, int P, int RC, bool SYNC_FIRST>
+__device__ __forceinline__ void reg3_forward(C<T> (&v)[P], T *img, const C<T> *__restrict__ tw, unsigned t)
 {
-    constexpr int L = P * RC, N = P * L, TC = P / RC, ROW = L + 32 / P, PLANE = P * P + (P < 32 ? 16 : 0);
+    constexpr int L = P * RC, TC = P / RC, ROW = L + 32 / P, PLANE = P * P + (P < 32 ? 16 : 0);
     static_assert(RC * TC == P && (P == 16 || P == 32), "whole last-radix transforms per lane");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T *img = reinterpret_cast<T *>(smem_raw);
-    const unsigned t = threadIdx.x, k1 = t % P, m0 = t / P;
-    const T sgn = (flags & kFftBackward) ? T(-1) : T(1);  // conjugate . forward . conjugate
-    const size_t f = blockIdx.x;
-    if (f >= batch) return;
-
-    C<T> v[P];
-    {
-        const C<T> *src = in + f * N + t;
-#pragma unroll
-        for (int j = 0; j < P; j++) {
-            C<T> q = (NTMEM & 1) ? nt_load(src + L * j) : src[L * j];
-            q.im *= sgn;
-            v[j] = q;
-        }
-    }
+    const unsigned k1 = t % P, m0 = t / P;
     // two factors for every W^(g k), k = 1 .. P - 1: k = 4 a + b
     auto twiddle = [&](unsigned g) {
         C<T> l3[3], h4[P / 4 - 1];
@@ -2244,7 +2231,7 @@ __global__ __launch_bounds__(P * RC) void fft_c2c_reg3_kernel(const C<T> *in, C<
         const T *rp = img + k1 * ROW + m0;    // n0 = m0 + RC m1
 #pragma unroll
         for (int comp = 0; comp < 2; comp++) {
-            if (comp) __syncthreads();
+            if (comp || SYNC_FIRST) __syncthreads();
 #pragma unroll
             for (int j = 0; j < P; j++) wp[j * ROW] = comp ? v[j].im : v[j].re;
             __syncthreads();
@@ -2279,6 +2266,31 @@ __global__ __launch_bounds__(P * RC) void fft_c2c_reg3_kernel(const C<T> *in, C<
     }
 #pragma unroll
     for (int i = 0; i < TC; i++) dft_reg<RC, 1>(&v[i * RC]);  // over m0 -> q0
+}
+
+template <typename T, int P, int RC, int NTMEM>
+__global__ __launch_bounds__(P * RC) void fft_c2c_reg3_kernel(const C<T> *in, C<T> *out, const C<T> *__restrict__ tw, size_t batch,
+                                                              int flags)
+{
+    constexpr int L = P * RC, N = P * L, TC = P / RC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *img = reinterpret_cast<T *>(smem_raw);
+    const unsigned t = threadIdx.x;
+    const T sgn = (flags & kFftBackward) ? T(-1) : T(1);  // conjugate . forward . conjugate
+    const size_t f = blockIdx.x;
+    if (f >= batch) return;
+
+    C<T> v[P];
+    {
+        const C<T> *src = in + f * N + t;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            C<T> q = (NTMEM & 1) ? nt_load(src + L * j) : src[L * j];
+            q.im *= sgn;
+            v[j] = q;
+        }
+    }
+    reg3_forward<T, P, RC, false>(v, img, tw, t);
     C<T> *dst = out + f * N + t;
 #pragma unroll
     for (int i = 0; i < TC; i++)
@@ -2286,9 +2298,94 @@ __global__ __launch_bounds__(P * RC) void fft_c2c_reg3_kernel(const C<T> *in, C<
         for (int q0 = 0; q0 < RC; q0++) {
             C<T> q = v[i * RC + q0];
             q.im *= sgn;
-            if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + L * i + P * P * q0);
-            else dst[L * i + P * P * q0] = q;
+            if constexpr ((NTMEM & 2) != 0) nt_store(q, dst + L * (i + TC * q0));
+            else dst[L * (i + TC * q0)] = q;
         }
+}
+
+// Any length n through an M-point convolution (bluestein_fused_kernel's arithmetic) with the frame in
+// registers: frame times chirp, zero-extended -> transform -> times the filter's spectrum ->
+// transform back -> times chirp, one read and one write of n points per frame.  The first
+// transform leaves every lane the bins t + L j it started with as samples, so the second follows in
+// registers.  Double precision, where the frame-image kernel does not fit: M = 512 .. 16384.
+template <typename T, int P, int RC>
+__global__ __launch_bounds__(P * RC) void bluestein_reg3_kernel(const C<T> *in, C<T> *out, const C<T> *__restrict__ chirp,
+                                                                const C<T> *__restrict__ filt, const C<T> *__restrict__ tw, unsigned n,
+                                                                size_t batch, int backward)
+{
+    constexpr int L = P * RC, TC = P / RC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T *img = reinterpret_cast<T *>(smem_raw);
+    const unsigned t = threadIdx.x;
+    const T sgn = backward ? T(-1) : T(1);  // backward = conj . forward . conj
+    const size_t f = blockIdx.x;
+    if (f >= batch) return;
+
+    C<T> v[P];
+    {
+        const C<T> *src = in + f * n;
+#pragma unroll
+        for (int j = 0; j < P; j++) {
+            const unsigned m = t + L * j;
+            C<T> q = {T(0), T(0)};
+            if (m < n) {
+                q = src[m];
+                q.im *= sgn;
+                q = cmul(q, chirp[m]);
+            }
+            v[j] = q;
+        }
+    }
+    reg3_forward<T, P, RC, false>(v, img, tw, t);
+    C<T> w[P];
+    {
+        const C<T> *fp = filt + t;
+#pragma unroll
+        for (int i = 0; i < TC; i++)
+#pragma unroll
+            for (int q0 = 0; q0 < RC; q0++) {
+                const int j = i + TC * q0;  // bin t + L j
+                const C<T> m = cmul(v[i * RC + q0], fp[L * j]);
+                w[j] = {m.re, -m.im};
+            }
+    }
+    reg3_forward<T, P, RC, true>(w, img, tw, t);
+    C<T> *dst = out + f * n;
+#pragma unroll
+    for (int i = 0; i < TC; i++)
+#pragma unroll
+        for (int q0 = 0; q0 < RC; q0++) {
+            const unsigned k = t + L * (i + TC * q0);
+            if (k < n) {
+                C<T> q = cmul(C<T>{w[i * RC + q0].re, -w[i * RC + q0].im}, chirp[k]);
+                q.im *= sgn;
+                dst[k] = q;
+            }
+        }
+}
+
+template <typename T, int P, int RC>
+int launch_bluestein_reg3(const void *in, void *out, const void *chirp, const void *filt, const void *tw, unsigned n, size_t batch,
+                          int backward, int num_cu, hipStream_t s)
+{
+    constexpr int L = P * RC, ROW = L + 32 / P, PLANE = P * P + (P < 32 ? 16 : 0);
+    constexpr size_t lds = (size_t)(P * ROW > RC * PLANE ? P * ROW : RC * PLANE) * sizeof(T);
+    auto kern = bluestein_reg3_kernel<T, P, RC>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr.mark();
+    }
+    (void)num_cu;
+    for (size_t done = 0; done < batch;) {
+        const size_t g = batch - done < 0x40000000u ? batch - done : 0x40000000u;
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(L), lds, s, static_cast<const C<T> *>(in) + done * n,
+                           static_cast<C<T> *>(out) + done * n, static_cast<const C<T> *>(chirp), static_cast<const C<T> *>(filt),
+                           static_cast<const C<T> *>(tw), n, g, backward);
+        DSPMI_HIP(hipGetLastError());
+        done += g;
+    }
+    return DSPMI_OK;
 }
 
 template <typename T, int P, int RC, int NTMEM>
@@ -2782,6 +2879,15 @@ fft_bundle_fn fft_bundle_find(unsigned n, int precision)
 
 bluestein_launch_fn bluestein_find(unsigned m, int precision)
 {
+    if (precision == DSPMI_F64) switch (m) {
+        case 512: return launch_bluestein_reg3<double, 16, 2>;
+        case 1024: return launch_bluestein_reg3<double, 16, 4>;
+        case 2048: return launch_bluestein_reg3<double, 16, 8>;
+        case 4096: return launch_bluestein_reg3<double, 16, 16>;
+        case 8192: return launch_bluestein_reg3<double, 32, 8>;
+        case 16384: return launch_bluestein_reg3<double, 32, 16>;
+        default: return nullptr;
+        }
     if (precision != DSPMI_F32) return nullptr;
     for (const BluesteinEntry &e : kBluesteinF32)
         if (e.m == m) return e.fn;

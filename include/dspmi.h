@@ -198,7 +198,8 @@ int dspmi_fft_exec_c2c(dspmi_fft_t plan, const void *in, void *out, size_t batch
  * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in
  * the reference.  Same arguments and results as dspmi_fft_exec_c2c; the difference is where
  * the multi-kernel transforms keep their work frames (the any-length transform in double
- * precision: batch * M * 16 bytes, M = the power of two >= 2n-1; powers of two beyond the
+ * precision where it is still several kernels -- M = the power of two >= 2n-1 up to 256:
+ * batch * M * 16 bytes; M = 512 .. 16384 is one kernel and needs none --; powers of two beyond the
  * longest single kernel: n points per frame -- f32 up to 2^21 points, f64 up to 2^20 --, frames
  * going through in groups that fit):
  * not in the plan's own buffer, which an execute may have to grow, but in a static device

@@ -17,7 +17,7 @@ def _frames(batch, n, dtype, seed):
     return torch.from_numpy(z.astype(dtype)).cuda()
 
 
-@pytest.mark.parametrize("n,dtype", [(480, "f64"), (482, "f64"), (1000, "f64"), (480, "f32"), (1024, "f64"), (32768, "f64"),
+@pytest.mark.parametrize("n,dtype", [(480, "f64"), (482, "f64"), (1000, "f64"), (100, "f64"), (480, "f32"), (1024, "f64"), (32768, "f64"),
                                      (65536, "f32"), (1 << 20, "f64"), (1 << 21, "f32")])
 def test_no_alloc_c2c_matches_the_allocating_entry_point(n, dtype):
     ct = np.complex128 if dtype == "f64" else np.complex64
@@ -38,20 +38,21 @@ def test_no_alloc_c2c_matches_the_allocating_entry_point(n, dtype):
 
 
 def test_no_alloc_c2c_in_place_and_limits():
-    n = 482
-    plan = dsp_amd.FftPlan(n, "f64")
+    n = 100   # double precision, M = 256: the five-kernel any-length transform with its work frames
+    plan = dsp_amd.FftPlan(n, "f64")   # (from M = 512 to 16384 one kernel does it all and needs none)
+    assert "via" in plan.variant
     z = _frames(9, n, np.complex128, 7)
     want = plan.c2c(z)
     buf = z.clone()
     plan.c2c_noalloc(buf, out=buf)
     assert torch.equal(torch.view_as_real(buf), torch.view_as_real(want))
-    # 482 points ride 1024-point work frames of 16 KiB: the 16 MiB array holds 1024 of them
+    # 100 points ride 256-point work frames of 4 KiB: the 16 MiB array holds 4096 of them
     L = dsp_amd.lib()
-    big = torch.empty((1025, n), dtype=torch.complex128, device="cuda")
-    rc = L.dspmi_fft_exec_c2c_noalloc(plan._h, big.data_ptr(), big.data_ptr(), 1025, -1, None)
+    big = torch.empty((4097, n), dtype=torch.complex128, device="cuda")
+    rc = L.dspmi_fft_exec_c2c_noalloc(plan._h, big.data_ptr(), big.data_ptr(), 4097, -1, None)
     assert rc == -22 and b"static" in L.dspmi_last_error()
-    ok = torch.empty((1024, n), dtype=torch.complex128, device="cuda").normal_()
-    assert L.dspmi_fft_exec_c2c_noalloc(plan._h, ok.data_ptr(), ok.data_ptr(), 1024, -1, None) == 0
+    ok = torch.empty((4096, n), dtype=torch.complex128, device="cuda").normal_()
+    assert L.dspmi_fft_exec_c2c_noalloc(plan._h, ok.data_ptr(), ok.data_ptr(), 4096, -1, None) == 0
     torch.cuda.synchronize()
     # a smaller call right after the largest one
     small = z[:2].clone()
@@ -59,7 +60,7 @@ def test_no_alloc_c2c_in_place_and_limits():
     assert torch.equal(torch.view_as_real(small), torch.view_as_real(want[:2]))
 
 
-@pytest.mark.parametrize("n,dtype,batch", [(482, "f64", 40), (65536, "f32", 6)])
+@pytest.mark.parametrize("n,dtype,batch", [(100, "f64", 40), (65536, "f32", 6)])
 def test_no_alloc_c2c_on_a_fresh_plan_leaves_device_memory_alone(n, dtype, batch):
     """The first execute of a plan, before any dspmi_fft_exec_c2c has grown the plan's own work
     buffers: the amount of free device memory is the same before and after (an entry point that fell

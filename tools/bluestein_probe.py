@@ -1,5 +1,5 @@
-"""c2c of lengths that are not powers of two (f32): the one-kernel Bluestein form against the five
-separate kernels, on about 2^27 complex points."""
+"""c2c of lengths that are not powers of two: the one-kernel Bluestein form against the five
+separate kernels, on about 1 GiB of frames:  tools/bluestein_probe.py [f32|f64]"""
 import os
 import sys
 
@@ -9,16 +9,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dsp_amd  # noqa: E402
 from tools.c2r_probe import timed  # noqa: E402
 
-for n in (100, 480, 482, 1000, 3000, 6000):
-    batch = (1 << 27) // n
-    z = torch.view_as_complex(torch.rand(batch, n, 2, device="cuda") - 0.5)
+dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+esz = 8 if dtype == "f32" else 16
+for n in (100, 200, 480, 482, 1000, 3000, 6000, 8000):
+    batch = (1 << 30) // (n * esz)
+    z = torch.view_as_complex(torch.rand(batch, n, 2, device="cuda", dtype=torch.float32 if dtype == "f32" else torch.float64) - 0.5)
     out = torch.empty_like(z)
-    plan = dsp_amd.FftPlan(n, "f32")
+    plan = dsp_amd.FftPlan(n, dtype)
     os.environ.pop("DSPMI_BLUESTEIN_COMPOSED", None)
     a = timed(lambda: plan.c2c(z, out=out), 5)
     os.environ["DSPMI_BLUESTEIN_COMPOSED"] = "1"
     b = timed(lambda: plan.c2c(z, out=out), 5)
     os.environ.pop("DSPMI_BLUESTEIN_COMPOSED", None)
-    gb = 16.0 * n * batch / 1e9
-    print("n=%5d x %7d (%s): one kernel %.3f ms = %.2f TB/s of 16 B/point | five kernels %.3f ms" % (
+    gb = 2.0 * esz * n * batch / 1e9
+    print("n=%5d x %7d (%s): one kernel %.3f ms = %.2f TB/s of one read + one write | five kernels %.3f ms" % (
         n, batch, plan.variant, a, gb / a, b), flush=True)
