@@ -2889,6 +2889,7 @@ bluestein_launch_fn bluestein_find(unsigned m, int precision)
         default: return nullptr;
         }
     if (precision != DSPMI_F32) return nullptr;
+    if (m == 32768) return launch_bluestein_reg3<float, 32, 32>;  // (no frame image of 32768 complex points fits the LDS)
     for (const BluesteinEntry &e : kBluesteinF32)
         if (e.m == m) return e.fn;
     return nullptr;

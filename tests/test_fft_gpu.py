@@ -302,13 +302,19 @@ def test_lengths_no_kernel_covers_are_refused():
         assert rel_l2(got, want) <= (TOL_FFT if dtype == "f32" else TOL_F64)
 
 
-@pytest.mark.parametrize("n,batch", [(5, 3), (9, 70), (100, 33), (480, 17), (482, 4), (1000, 9), (3000, 5), (8191, 2)])
-def test_any_length_one_kernel_form(n, batch, monkeypatch):
-    """Lengths that are not powers of two run Bluestein's convolution in one kernel (f32); the five
-    separate kernels are the same arithmetic.  Both directions, ragged batches, in place."""
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("n,batch", [(5, 3), (9, 70), (100, 33), (129, 5), (300, 7), (480, 17), (482, 4), (1000, 9), (3000, 5), (8191, 2),
+                                     (12000, 3), (16384 - 5, 2)])
+def test_any_length_one_kernel_form(n, batch, dtype, monkeypatch):
+    """Lengths that are not powers of two run Bluestein's convolution in one kernel (f32 up to
+    M = 32768 points of convolution, f64 for M = 512 .. 16384); the five separate kernels are the
+    same arithmetic.  Both directions, ragged batches, in place."""
+    TOL_FFT = 1e-5 if dtype == "f32" else TOL_F64   # noqa: N806 - shadows the module's f32 tolerance for this dtype
     rng = np.random.default_rng(n * 7 + batch)
-    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64)
-    plan = dsp_amd.FftPlan(n, "f32")
+    z = (rng.uniform(-1, 1, (batch, n)) + 1j * rng.uniform(-1, 1, (batch, n))).astype(np.complex64 if dtype == "f32" else np.complex128)
+    plan = dsp_amd.FftPlan(n, dtype)
+    if dtype == "f32" or 256 < n <= 8192:
+        assert "one_kernel" in plan.variant
     zd = torch.from_numpy(z).cuda()
     fwd = plan.c2c(zd, dsp_amd.FORWARD)
     bwd = plan.c2c(zd, dsp_amd.BACKWARD)

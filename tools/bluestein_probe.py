@@ -11,7 +11,7 @@ from tools.c2r_probe import timed  # noqa: E402
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 esz = 8 if dtype == "f32" else 16
-for n in (100, 200, 480, 482, 1000, 3000, 6000, 8000):
+for n in (100, 200, 480, 482, 1000, 2000, 3000, 6000, 8000, 12000, 16000):
     batch = (1 << 30) // (n * esz)
     z = torch.view_as_complex(torch.rand(batch, n, 2, device="cuda", dtype=torch.float32 if dtype == "f32" else torch.float64) - 0.5)
     out = torch.empty_like(z)
