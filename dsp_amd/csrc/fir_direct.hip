@@ -501,6 +501,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int kSplitMaxSlices = 10;
 constexpr int kHalfMaxSlices = 17;  // the f16 kernel alone: its tap images are 8 registers a slice
+constexpr int kHalfLdsMaxSlices = 32;  // ... or 2 KB of LDS a slice (fir_half_lds_kernel)
 constexpr size_t split_lds_bytes(int ns) { return (size_t)2 * 3 * (kSplitTile + 32 * ns - 16) * 2; }  // two sets of three planes
 
 // bf16(lo) in the low half, bf16(hi) in the high half, both rounded to nearest even
@@ -792,6 +793,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NS <= 5 ? 4
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     StoreSink<TILE> sink(p);
     fir_half_tiles<NS, StoreSink<TILE>, MemorySource, TILE>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
+}
+
+// 18 .. 32 slices (530 .. 1009 taps): the tap images in LDS, tiles of 1024 outputs (the window of a
+// tile is up to 1008 samples longer than the tile, and two workgroups still fit a CU).
+template <int NS>
+__global__ __launch_bounds__(256) void fir_half_lds_kernel(const FirParams<float> p, const u32x4 *__restrict__ htab, float tap_unscale)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    StoreSink<1024> sink(p);
+    fir_half_tiles<NS, StoreSink<1024>, MemorySource, 1024, true>(p, htab, tap_unscale, smem_raw, sink, MemorySource{});
 }
 
 }  // namespace
@@ -1267,6 +1278,41 @@ int launch_half(const FirParams<float> &p, const void *tab, float unscale, int n
 }
 
 template <int NS>
+int launch_half_lds_t(const FirParams<float> &p, const void *tab, float unscale, unsigned blocks, hipStream_t stream)
+{
+    const size_t lds = half_lds_bytes(NS, 1024) + half_taps_lds_bytes(NS);
+    auto kern = fir_half_lds_kernel<NS>;
+    static dspmi::PerDeviceOnce attr;
+    if (attr.pending()) {
+        DSPMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, stream, p, static_cast<const u32x4 *>(tab), unscale);
+    DSPMI_HIP(hipGetLastError());
+    return DSPMI_OK;
+}
+
+int launch_half_lds(FirParams<float> p, const void *tab, float unscale, int ns, unsigned nchan, hipStream_t stream)
+{
+    p.tiles_per_chan = (unsigned)(((unsigned long long)p.nxx + 1023) / 1024);
+    const unsigned long long tiles = (unsigned long long)p.tiles_per_chan * nchan;
+    if (tiles == 0) return DSPMI_OK;
+    if (tiles > 0x7fffffffull) return dspmi::fail(DSPMI_EINVAL, "fir: %llu tiles exceed the grid limit", tiles);
+    p.ntiles_total = (unsigned)tiles;
+    // a workgroup copies the tap images (2 KB a slice) into LDS before its first tile: walks of 4 .. 64 tiles
+    const unsigned long long tpb = tiles / 512;
+    p.tiles_per_block = (unsigned)(tpb < 4 ? 4 : tpb > 64 ? 64 : tpb);
+    const unsigned blocks = (unsigned)((tiles + p.tiles_per_block - 1) / p.tiles_per_block);
+    switch (ns) {
+#define DSPMI_CASE(N) case N: return launch_half_lds_t<N>(p, tab, unscale, blocks, stream);
+        DSPMI_CASE(18) DSPMI_CASE(19) DSPMI_CASE(20) DSPMI_CASE(21) DSPMI_CASE(22) DSPMI_CASE(23) DSPMI_CASE(24) DSPMI_CASE(25)
+        DSPMI_CASE(26) DSPMI_CASE(27) DSPMI_CASE(28) DSPMI_CASE(29) DSPMI_CASE(30) DSPMI_CASE(31) DSPMI_CASE(32)
+#undef DSPMI_CASE
+    }
+    return dspmi::fail(DSPMI_EINVAL, "fir: no f16 kernel of %d slices", ns);
+}
+
+template <int NS>
 int launch_split_t(const FirParams<float> &p, const void *tab, unsigned blocks, hipStream_t stream)
 {
     size_t lds = split_lds_bytes(NS);
@@ -1392,7 +1438,7 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
         pl->variant = valu ? (nh <= 32 ? V_F32_SHORT : V_F32_LONG) : V_F32_MFMA;
         pl->pinned = valu || mfma;
         if constexpr (sizeof(T) == 4) {
-            const unsigned split_max = 32 * ((env && !strcmp(env, "f16")) ? kHalfMaxSlices : kSplitMaxSlices) - 15;
+            const unsigned split_max = 32 * ((env && !strcmp(env, "f16")) ? kHalfLdsMaxSlices : kSplitMaxSlices) - 15;
             // (plans below the f16 kernel's own range hold its tap images too, for the fused filter +
             // spectrum entry point; their FIR calls keep the f32 kernels)
             const bool tables_only = !env && nh < kSplitAutoMinTaps;
@@ -1401,10 +1447,13 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
             // 400, 343 at 511, whatever the row length from 4096 samples on -- where overlap-save runs
             // 210-330 on rows of up to 65536 samples and 420-470 on rows of 2^20.  Such plans hold
             // both, and a call takes the f16 kernel for rows below the measured crossover.
-            const bool mid_rows = !env && !(opts & DSPMI_FIR_FULL_RANGE) && nh > 32 * kSplitMaxSlices - 15 && nh <= 32 * kHalfMaxSlices - 15;
+            const bool mid_rows = !env && !(opts & DSPMI_FIR_FULL_RANGE) && nh > 32 * kSplitMaxSlices - 15 && nh <= 32 * kHalfLdsMaxSlices - 15;
             if (!valu && !mfma && !want_ols && (nh >= (want_split ? 1u : kSplitAutoMinTaps) || tables_only) && (nh <= split_max || mid_rows)) {
                 pl->half_exec = !tables_only && !mid_rows;
-                if (mid_rows) pl->half_rows_below = nh <= 32 * 13 - 15 ? (1u << 19) : (1u << 17);
+                if (mid_rows) {
+                    const unsigned slices = (nh + 15 + 31) / 32;
+                    pl->half_rows_below = slices <= 13 ? (1u << 19) : slices <= kHalfMaxSlices ? (1u << 17) : slices <= 22 ? 32768u : slices <= 26 ? 16384u : 8192u;
+                }
                 pl->split_ns = (int)((nh + 15 + 31) / 32);
                 const std::vector<unsigned short> img = want_half ? half_tap_images(taps, nh, pl->split_ns, &pl->half_unscale)
                                                                   : split_tap_images(taps, nh, pl->split_ns);
@@ -1485,8 +1534,11 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
     if constexpr (sizeof(T) == 4) {
         // overlap-save covers the plain case: as many outputs as inputs, rows long enough to
         // fill a few transforms; tails past the input, the conv1 form and short rows stay direct
-        if (pl->half_rows_below && flags == 0 && nx < pl->half_rows_below)
-            return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
+        auto run_half = [&]() {
+            return pl->split_ns <= kHalfMaxSlices ? launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s)
+                                                  : launch_half_lds(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
+        };
+        if (pl->half_rows_below && flags == 0 && nx < pl->half_rows_below) return run_half();
         if (pl->ols && flags == 0 && nxx == nx) {
             const unsigned long long work = (unsigned long long)nx * pl->nh;
             if (nx >= 2 * pl->ols_n && !(pl->ols_small && nx < 8 * pl->ols_n))
@@ -1514,7 +1566,7 @@ int exec(dspmi_fir_t pl, T *y, size_t y_stride, unsigned nxx, const T *x, size_t
                 return dspmi_ols_exec_f32(pl->ols, y, y_stride, x, x_stride, nx, nchan, hist, hist_stride, stream);
             }
         }
-        if (pl->half_tab && pl->half_exec && flags == 0) return launch_half(p, pl->half_tab, pl->half_unscale, pl->split_ns, nchan, s);
+        if (pl->half_tab && (pl->half_exec || pl->half_rows_below) && flags == 0) return run_half();  // (also what overlap-save leaves: tails past the input, rows that start from zero state)
         if (pl->split_tab && flags == 0) return launch_split(p, pl->split_tab, pl->split_ns, nchan, s);
         if (pl->variant == V_F32_MFMA) {
             if (!pl->pinned && stream_applies(p)) return launch_stream<float, false>(p, nchan, s);

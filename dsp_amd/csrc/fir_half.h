@@ -66,6 +66,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_descriptor(const void 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+constexpr size_t half_taps_lds_bytes(int ns) { return (size_t)ns * 2 * 64 * 16; }
 constexpr size_t half_lds_bytes(int ns, int tile = kSplitTile) { return (size_t)2 * 2 * (tile + 32 * ns - 16) * 2 + 64; }  // two sets of two planes + the maxima (a multiple of 64)
 
 // f16(lo) in the low half, f16(hi) in the high half, both rounded to nearest even
@@ -153,7 +154,10 @@ struct ToneSource {
 // TILE: outputs per workgroup step, 1024 BLK with BLK = 4 (the default), 2 or 1 blocks of 256
 // outputs per wave: rows much shorter than 4096 samples fill short tiles where they would leave
 // most of a long one empty (the sink numbers its outputs by the same TILE).
-template <int NS, class Sink, class Source, int TILE = kSplitTile>
+// TAPS_LDS: the tap images (8 registers a slice) stay in LDS behind the planes and the sink's share
+// -- half_taps_lds_bytes(NS) more -- and are read two steps ahead like the window: what filters of
+// 18 .. 32 slices (530 .. 1009 taps) need, whose images no register file holds.
+template <int NS, class Sink, class Source, int TILE = kSplitTile, bool TAPS_LDS = false>
 __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const u32x4 *__restrict__ htab, float tap_unscale,
                                                char *smem_raw, Sink &sink, const Source &src)
 {
@@ -174,11 +178,16 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
     const unsigned lane = t & 63, wave = t >> 6;
     const long nx = p.nx, nh = p.nh;
 
-    f16x8 hf[NS][2];
+    f16x8 hf[TAPS_LDS ? 1 : NS][2];
+    u32x4 *taps_lds = reinterpret_cast<u32x4 *>(smem_raw + half_lds_bytes(NS, TILE));  // TAPS_LDS: [NS][2][64]
+    if constexpr (TAPS_LDS) {
+        for (unsigned i = t; i < (unsigned)NS * 128; i += 256) taps_lds[i] = htab[i];  // (the prologue's barrier follows)
+    } else {
 #pragma unroll
-    for (int s = 0; s < NS; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++) hf[s][pl] = __builtin_bit_cast(f16x8, htab[(s * 2 + pl) * 64 + lane]);
+            for (int pl = 0; pl < 2; pl++) hf[s][pl] = __builtin_bit_cast(f16x8, htab[(s * 2 + pl) * 64 + lane]);
+    }
 
     const long tile_lo = (long)blockIdx.x * p.tiles_per_block;
     const long tile_hi = min(tile_lo + (long)p.tiles_per_block, (long)p.ntiles_total);
@@ -381,10 +390,12 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
 #pragma unroll
         for (int it = 0; it < NIT; it++) load_piece(cur, it);
     }
+    if constexpr (!TAPS_LDS) {
 #pragma unroll
-    for (int s = 0; s < NS; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++) asm volatile("" : "+v"(hf[s][pl]));  // landed before the loop (see fir_split_kernel)
+            for (int pl = 0; pl < 2; pl++) asm volatile("" : "+v"(hf[s][pl]));  // landed before the loop (see fir_split_kernel)
+    }
     publish_max(0);
     __syncthreads();
     float scale_nxt, unscale_cur, unscale_nxt;
@@ -412,7 +423,7 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
         const Unit nxt2 = describe();
         scales(unit + 1, scale_nxt, unscale_nxt);
         sink.begin_tile(cur.chan, cur.tile_start, unscale_cur);
-        f16x8 xf[3][2];
+        f16x8 xf[3][2], af[TAPS_LDS ? 3 : 1][2];
         f32x4 big[BLK], small[BLK];
         const unsigned short *xp = rd_planes + b_base;
         auto rd = [&](int step) {
@@ -420,6 +431,10 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
 #pragma unroll
             for (int pl = 0; pl < 2; pl++)
                 xf[step % 3][pl] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(xp + pl * NSTAGE + off));
+            if constexpr (TAPS_LDS) {
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) af[step % 3][pl] = __builtin_bit_cast(f16x8, taps_lds[((step % NS) * 2 + pl) * 64 + lane]);
+            }
         };
         auto store = [&](int q) {
             f32x4 res;
@@ -437,9 +452,10 @@ __device__ __forceinline__ void fir_half_tiles(const FirParams<float> &p, const 
             __builtin_amdgcn_sched_barrier(0);
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             f32x4 sm = s ? small[q] : zero, bg = s ? big[q] : zero;
-            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][0], xf[slot][1], sm, 0, 0, 0);
-            bg = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][0], xf[slot][0], bg, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf[s][1], xf[slot][0], sm, 0, 0, 0);
+            const f16x8 h0 = TAPS_LDS ? af[slot][0] : hf[TAPS_LDS ? 0 : s][0], h1 = TAPS_LDS ? af[slot][1] : hf[TAPS_LDS ? 0 : s][1];
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xf[slot][1], sm, 0, 0, 0);
+            bg = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, xf[slot][0], bg, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, xf[slot][0], sm, 0, 0, 0);
             small[q] = sm;
             big[q] = bg;
             // one piece per step from the first step on (all of them at once where a tile has

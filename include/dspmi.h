@@ -89,16 +89,18 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  *                   flags == 0, nxx == nx and the rows hold enough work (up to 899 taps: two
  *                   transforms of four times the tap count; from 900 taps: nx * nh >= 4e5, in
  *                   blocks of 16384 samples, of 32768 from rows of 65536 samples); any other
- *                   call, and longer filters, run the f32 kernel.  306 .. 529 taps on rows shorter
- *                   than 2^19 samples (from 402 taps: 2^17) run the f16 kernel of the line above
- *                   instead, which is faster there; its contract applies to those calls.
+ *                   call, and longer filters, run the f32 kernel.  306 .. 1009 taps on short rows
+ *                   run the f16 kernel of the line above instead, which is faster there (rows
+ *                   shorter than 2^19 samples up to 401 taps, 2^17 up to 529, 32768 up to 689, 16384
+ *                   up to 817, 8192 beyond; also the calls overlap-save does not take: tails past
+ *                   the input, rows that start from zero state); its contract applies to those calls.
  * DSPMI_FIR_VARIANT = mfma | f16 | bf16 | ols in the environment at creation pins the f32 kernel,
  * the f16 kernel, its three-part bf16 sibling (no scale, full f32 exponent range) or overlap-save. */
 int dspmi_fir_create_f32(dspmi_fir_t *plan, const float *taps, unsigned nh, int device);
 /* The same with options:
  *   DSPMI_FIR_FULL_RANGE    never the f16 kernel: 33 .. 305 taps run its sibling with three bf16 parts
  *                           per operand and no scale -- products exact to 2^-24 over the whole f32
- *                           exponent range, about 20 % slower at 127 taps; 306 .. 529 taps keep
+ *                           exponent range, about 20 % slower at 127 taps; 306 .. 1009 taps keep
  *                           overlap-save and the f32 kernel on every row length;
  *   DSPMI_FIR_F32_PRODUCTS  every tap count on the f32 matrix kernel: f32 products, f32 sums.
  * In the two matrix kernels these options select, a non-finite sample makes the outputs of the

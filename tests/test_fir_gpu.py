@@ -711,13 +711,14 @@ def test_fir_and_spectrum_kernel_with_a_non_finite_sample():
         assert np.isfinite(got[c, f]).all() and rel_l2(got[c, f], want[c, f]) <= 1e-5, (c, f)
 
 
-@pytest.mark.parametrize("nh", [306, 417, 529])
-@pytest.mark.parametrize("nx", [700, 4096, 9000])
+@pytest.mark.parametrize("nh", [306, 417, 529, 530, 700, 964, 1009])
+@pytest.mark.parametrize("nx", [700, 4096, 7000])
 def test_mid_length_filters_on_short_rows_run_the_f16_kernel(nh, nx):
-    """306 .. 529 taps (11 .. 17 slices): the plan is an overlap-save plan that also holds the f16
-    kernel's tap images and runs it on rows below the measured crossover -- with carried history,
-    with the nx + nh tail, and against the same plan created with DSPMI_FIR_FULL_RANGE, which keeps
-    overlap-save and the f32 kernels (fir/src/main.c:258-280 is the sum both restate)."""
+    """306 .. 1009 taps (11 .. 32 slices; from 18 slices the tap images sit in LDS): the plan is an
+    overlap-save plan that also holds the f16 kernel's tap images and runs it on rows below the
+    measured crossover -- with carried history, with the nx + nh tail, and against the same plan
+    created with DSPMI_FIR_FULL_RANGE, which keeps overlap-save and the f32 kernels
+    (fir/src/main.c:258-280 is the sum both restate; :324 applies a 964-point kernel)."""
     rng = np.random.default_rng(nh + nx)
     nchan = 19
     x = rng.uniform(-1, 1, (nchan, nx)).astype(np.float32)
