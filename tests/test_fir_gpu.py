@@ -90,7 +90,7 @@ def test_wrappers_keep_plans_between_calls_and_release_them():
     taps = [rng.standard_normal(nh) for nh in (16, 21, 5, 127, 16, 964)]   # two different 16-tap sets
     free0 = None
     for rnd in range(3):
-        if rnd == 1:   # round 0 also loaded the kernels and set up the library's own state: measure from here
+        if rnd == 1:   # the first pass also loaded the kernels and set up the library's own state: measure from here
             torch.cuda.synchronize()
             free0, _ = torch.cuda.mem_get_info()
         for i in (0, 1, 2, 3, 4, 5, 0, 4, 1):

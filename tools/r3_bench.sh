@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 measurement pass: the whole GPU test suite, the default bench, the same under
+# Measurement pass: the whole GPU test suite, the default bench, the same under
 # rocprofv3 --kernel-trace --stats, and the HBM-traffic counter passes of the default run.
 # Usage: tools/r3_bench.sh <tag>
 set -o pipefail
