@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the FIR / FFT hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload fft1024|fir127|fir16|ols8191|fir8191|chain|ols8191_split|c1]
+    python bench.py --gpus N --steps K --warmup W [--workload fft1024|fir127|fir16|ols8191|fir8191|chain|ols8191_split|c1|fft_len --fft-n N --fft-dtype f32|f64]
 
 One "step" is one pass of the hot path over one batch of synthetic input that
 is already resident in HBM.  The default workload is BASELINE.json configs[1]:
@@ -59,7 +59,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="fft1024", choices=["fft1024", "fir127", "fir127_direct", "fir16", "c1", "fir8191", "ols8191",
-                                                             "ols8191_split", "chain"])
+                                                             "ols8191_split", "chain", "fft_len"])
+    ap.add_argument("--fft-n", type=int, default=16384, help="fft_len workload: points per frame (1 GiB of frames per GPU)")
+    ap.add_argument("--fft-dtype", default="f32", choices=["f32", "f64"], help="fft_len workload: precision")
     ap.add_argument("--ols-n", type=int, default=0, help="8191-tap overlap-save: transform length (0 = the plan's choice)")
     ap.add_argument("--chain-two-kernels", action="store_true", help="chain workload: FIR and real transform as two kernels (A/B)")
     ap.add_argument("--chain-separate-generator", action="store_true",
@@ -607,6 +609,9 @@ def main():
 
     if args.workload == "fft1024":
         fn, info, keep = make_fft(args, rank)
+    elif args.workload == "fft_len":
+        fn, info, keep = make_fft_len(args.fft_n, args.fft_dtype)
+        args.no_secondary = True
     elif args.workload == "chain":
         fn, info, keep = make_chain(args, rank)
         args.no_secondary = True
@@ -679,7 +684,7 @@ def main():
     cpu = None
     extra = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_fft() if args.workload == "fft1024" else cpu_baseline_fir(info["nh"])
+        cpu = cpu_baseline_fft() if args.workload == "fft1024" else None if args.workload == "fft_len" else cpu_baseline_fir(info["nh"])
         try:
             extra["cpu_fir_as_shipped"] = cpu_as_shipped()
         except (OSError, AttributeError) as e:
@@ -688,9 +693,9 @@ def main():
             extra["pcie_inclusive"] = pcie_inclusive_fft()
 
     if rank == 0:
-        is_fft = args.workload == "fft1024"
+        is_fft = args.workload in ("fft1024", "fft_len")
         if is_fft:
-            metric = "FFT GFLOP/s (N=1024, c2c f32, 5*N*log2(N) flop per frame)"
+            metric = "FFT GFLOP/s (N=%d, c2c %s, 5*N*log2(N) flop per frame)" % (info["n"], args.fft_dtype if args.workload == "fft_len" else "f32")
         elif args.workload == "chain":
             metric = "Gsamples/s through the tonegen -> FIR -> FFT(4096) -> spectrum chain (f32)"
         else:
@@ -702,7 +707,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if args.workload == "ols8191_split" else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.fft_dtype if args.workload == "fft_len" else "f32", "data": "synthetic",
             "config": {"workload": info["workload"], "kernel": info["kernel"], "per_gpu_units": info["units"],
                        "unit_name": info["unit_name"],
                        "sharding": ("one signal cut into halo'd output segments, one all_gather of the outputs"
