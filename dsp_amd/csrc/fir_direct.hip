@@ -1452,7 +1452,7 @@ int create(dspmi_fir_t *out, const T *taps, unsigned nh, int device, int precisi
                 pl->half_exec = !tables_only && !mid_rows;
                 if (mid_rows) {
                     const unsigned slices = (nh + 15 + 31) / 32;
-                    pl->half_rows_below = slices <= 13 ? (1u << 19) : slices <= kHalfMaxSlices ? (1u << 17) : slices <= 22 ? 32768u : slices <= 26 ? 16384u : 8192u;
+                    pl->half_rows_below = slices <= 13 ? (1u << 19) : slices <= kHalfMaxSlices ? (1u << 17) : slices <= 20 ? 32768u : slices <= 26 ? 16384u : nh < kOlsLongMinTaps ? 12288u : 8192u;
                 }
                 pl->split_ns = (int)((nh + 15 + 31) / 32);
                 const std::vector<unsigned short> img = want_half ? half_tap_images(taps, nh, pl->split_ns, &pl->half_unscale)

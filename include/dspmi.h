@@ -91,8 +91,8 @@ typedef struct dspmi_fir_plan *dspmi_fir_t;
  *                   blocks of 16384 samples, of 32768 from rows of 65536 samples); any other
  *                   call, and longer filters, run the f32 kernel.  306 .. 1009 taps on short rows
  *                   run the f16 kernel of the line above instead, which is faster there (rows
- *                   shorter than 2^19 samples up to 401 taps, 2^17 up to 529, 32768 up to 689, 16384
- *                   up to 817, 8192 beyond; also the calls overlap-save does not take: tails past
+ *                   shorter than 2^19 samples up to 401 taps, 2^17 up to 529, 32768 up to 625, 16384
+ *                   up to 817, 12288 up to 899, 8192 beyond; also the calls overlap-save does not take: tails past
  *                   the input, rows that start from zero state); its contract applies to those calls.
  * DSPMI_FIR_VARIANT = mfma | f16 | bf16 | ols in the environment at creation pins the f32 kernel,
  * the f16 kernel, its three-part bf16 sibling (no scale, full f32 exponent range) or overlap-save. */

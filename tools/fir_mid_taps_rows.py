@@ -14,7 +14,7 @@ import oracle   # noqa: E402
 total = 1 << 27
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 taps = [int(a) for a in sys.argv[1:]] or [306, 400, 511, 625]
-ROWS = (1024, 4096, 16384, 32768, 65536, 131072, 262144, 1 << 20)
+ROWS = tuple(int(r) for r in os.environ["ROWS"].split(",")) if "ROWS" in os.environ else (1024, 4096, 16384, 32768, 65536, 131072, 262144, 1 << 20)
 for nh in taps:
     h = oracle.windowed_sinc_taps(nh).astype(np.float32)
     for pin in (None, "f16"):
